@@ -1,0 +1,216 @@
+/*
+ * unite_hip.h -- C ABI of libunite_hip.so: the MI355X (gfx950) kernels under UNITE's
+ * data-parallel training hot path (reddyav1/unite: run_stage1.py:294-505 and the model
+ * code it calls).  The reference has no FFI of its own: every op below replaces an
+ * ATen/cuDNN call the reference reaches through torch.nn (file:line cited per entry).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch owns the memory);
+ *     the library never allocates, frees or synchronises; workspace is passed in.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 on success, a negative UNITE_E* code for bad arguments, or a
+ *     positive hipError_t from the launch.  Nothing throws across the boundary.
+ *   - matrices are row-major; "bf16" is the upper 16 bits of an IEEE f32 (uint16_t storage).
+ *   - all leading dimensions and column counts of bf16 matrices must be multiples of 8
+ *     (16-byte rows), base pointers 16-byte aligned, and every buffer < 2 GiB.
+ */
+#ifndef UNITE_HIP_H
+#define UNITE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNITE_OK 0
+#define UNITE_EINVAL (-1)     /* bad shape / alignment / null pointer */
+#define UNITE_ENOSUP (-2)     /* shape outside what the kernels were built for */
+
+#define UNITE_ABI_VERSION 1
+int unite_abi_version(void);
+/* name of the code-object target the library was built for ("gfx950") */
+const char* unite_target_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM  out[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] ),  bf16 operands, f32 accumulate (MFMA).
+ *   trans_a = 0 : A stored [M,K] (lda >= K)        trans_a = 1 : A stored [K,M] (lda >= M)
+ *   trans_b = 0 : B stored [N,K] (ldb >= K), i.e. an nn.Linear weight [out,in]
+ *   trans_b = 1 : B stored [K,N] (ldb >= N)
+ * Replaces F.linear / nn.Linear / Conv3d-as-GEMM / x @ proj and their autograd backward:
+ *   modeling_finetune.py:106,117 (qkv, proj), :67,71 (fc1, fc2), :165-174 (patch embed),
+ *   modeling_adaptation.py:204 (decoder head), clip.py:38-44,123-128,170.
+ * Epilogue, applied in this order on the f32 accumulator v:
+ *   v += bias[n]                                   (bias != NULL)
+ *   act == UNITE_ACT_GELU      : if aux_out: aux_out[m,n] = bf16(v); v = gelu_erf(v)
+ *   act == UNITE_ACT_QUICKGELU : v = v * sigmoid(1.702 v)                       (clip.py:29-31)
+ *   act == UNITE_ACT_DGELU     : v *= gelu_erf'(aux_in[m,n])                    (backward of fc1)
+ *   v *= row_scale[m / rows_per_scale]             (row_scale != NULL; stochastic depth)
+ *   v += residual[m,n]                             (residual != NULL, f32, ld = ldr)
+ *   v += out[m,n]                                  (accumulate != 0, f32 out only)
+ *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given.
+ * ------------------------------------------------------------------------------------ */
+enum { UNITE_ACT_NONE = 0, UNITE_ACT_GELU = 1, UNITE_ACT_QUICKGELU = 2, UNITE_ACT_DGELU = 3 };
+
+typedef struct unite_gemm_args {
+    int32_t M, N, K;
+    int32_t trans_a, trans_b;
+    const void* A; int32_t lda;
+    const void* B; int32_t ldb;
+    const float* bias;
+    int32_t act;
+    const void* aux_in;  int32_t ld_aux_in;     /* bf16 [M,N] */
+    void* aux_out;       int32_t ld_aux_out;    /* bf16 [M,N] */
+    const float* row_scale; int32_t rows_per_scale;
+    const float* residual;  int32_t ldr;
+    void* out; int32_t ldc; int32_t out_f32; int32_t accumulate;
+    void* out_bf16_copy; int32_t ld_copy;
+} unite_gemm_args;
+
+int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (D % 4 == 0, D <= 1024), one wavefront per row, fp32 statistics.
+ *   y[i,:] = LN(x[src(i),:]) * gamma + beta (+ post_add[i,:]),  src(i) = row_index ? row_index[i] : i
+ * Replaces nn.LayerNorm: modeling_finetune.py:127,133 / modeling_adaptation.py:168 (eps 1e-6),
+ * clip.py:20-26,152,168 (eps 1e-5, fp32-forced).  mean/rstd (f32 [M]) are saved for backward when given.
+ * ------------------------------------------------------------------------------------ */
+int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index,
+                        const float* gamma, const float* beta, float eps,
+                        const float* post_add,            /* f32 [M,D] or NULL */
+                        void* y, int32_t y_f32,           /* [M,D] bf16 or f32 */
+                        float* mean, float* rstd,         /* [M] or NULL */
+                        int32_t M, int32_t D, void* stream);
+
+/* Backward of y = LN(x)*gamma+beta.  dy is bf16 (dy_f32 == 0) or f32 [M,D].
+ *   dx_out[i,:] = (dx_residual ? dx_residual[i,:] : 0) + dLN/dx
+ *   dx_bf16[i,:] = bf16(row_scale[i / rows_per_scale] * dx_out[i,:])      (optional)
+ *   dgamma/dbeta (f32 [D]) are OVERWRITTEN (accumulate == 0) or added to; partial sums go
+ *   through `workspace` (>= unite_layernorm_bwd_workspace(M, D) bytes) -> deterministic. */
+size_t unite_layernorm_bwd_workspace(int32_t M, int32_t D);
+int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* x, int32_t ldx,
+                        const float* mean, const float* rstd, const float* gamma,
+                        const float* dx_residual, float* dx_out,
+                        void* dx_bf16, const float* row_scale, int32_t rows_per_scale,
+                        float* dgamma, float* dbeta, int32_t accumulate,
+                        void* workspace, int32_t M, int32_t D, void* stream);
+
+/* Column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m x[m,n].
+ * workspace >= unite_colsum_workspace(M, N) bytes. */
+size_t unite_colsum_workspace(int32_t M, int32_t N);
+int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+                      void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused multi-head self-attention on a packed qkv matrix [B*N, 3*H*64] (bf16, row = token,
+ * columns = [q | k | v] x [head] x [64]); softmax(q k^T * scale) v, head_dim = 64, N <= 320.
+ * Replaces modeling_finetune.py:107-116 and nn.MultiheadAttention (clip.py:38,48-53).
+ *   out  : bf16 [B*N, H*64];   lse : f32 [B, H, N] (log-sum-exp of the scaled scores, for backward)
+ * ------------------------------------------------------------------------------------ */
+int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                   void* stream);
+/* Backward: dqkv (bf16 [B*N, 3*H*64]) from dout (bf16 [B*N, H*64]); recomputes the probabilities
+ * from qkv and lse.  delta (f32 [B,H,N]) is workspace. */
+int unite_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                   void* dqkv, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+/* Head-averaged softmax probabilities of query row 0 (CLS) over key columns 1..N-1:
+ * probs f32 [B, N-1].  Replaces need_weights=True + attn[:,0,1:] (clip.py:51,95-96,183). */
+int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch rows ("im2col") of a (B,3,T,H,W) f32 clip for a Conv3d with kernel = stride = (1,P,P):
+ *   cols[i, c*P*P + ph*P + pw] = bf16(video[b, c, t, gh*P+ph, gw*P+pw]),  token = token_index ?
+ *   token_index[i] : i,  token = ((b*T + t)*GH + gh)*GW + gw.   Only the listed tokens are read
+ * (the reference embeds all 1568 and drops 80 % two lines later: modeling_finetune.py:174,
+ * modeling_adaptation.py:153).
+ * ------------------------------------------------------------------------------------ */
+int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols,
+                        int32_t n_rows, int32_t B, int32_t T, int32_t H, int32_t W, int32_t P, void* stream);
+
+/* out[i,:] = table[(index[i] % modulo), :]   (f32, D % 4 == 0) -- sinusoid position rows of the
+ * visible tokens (modeling_adaptation.py:144,153,318-319). */
+int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modulo, float* out,
+                          int32_t n_rows, int32_t D, void* stream);
+
+/* CLIP token assembly + ln_pre (clip.py:148-152): patches bf16 [BT*HW, D] ->
+ * x f32 [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding). */
+int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,
+                        const float* gamma, const float* beta, float eps, float* x,
+                        int32_t BT, int32_t HW, int32_t D, void* stream);
+
+/* rows /= ||row||_2  (f32 [M,D], in place; clip.py:172-173). */
+int unite_l2_normalize_rows(float* x, int32_t M, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention-guided mask sampling (run_stage1.py:379-387): per frame row of `weights`
+ * (f32 [BT, N], N <= 256) draw a weighted permutation without replacement and keep its first
+ * n_vis entries visible.  Implemented as an exponential race (key = -log(u)/w, keep the n_vis
+ * smallest): the same distribution as torch.multinomial(w, N)[:, :n_vis] as a SET.
+ *   mask    : uint8 [BT*N], 1 = masked          vis_tokens : int32 [BT*n_vis] global token ids
+ *   (bt*N + j), ascending -- the row order of x[~mask] (modeling_adaptation.py:153).
+ * ------------------------------------------------------------------------------------ */
+int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens,
+                      int32_t BT, int32_t N, int32_t n_vis, void* stream);
+/* Same outputs from an explicit permutation (int64 [BT,N], the reference's `importance`). */
+int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens,
+                               int32_t BT, int32_t N, int32_t n_vis, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decoder tail + UMT loss (modeling_adaptation.py:204-207, run_stage1.py:431):
+ *   u = LN_eps(y) * gamma + beta ;  o = u / ||u||_2 ;  loss_sum += sum_rows (2 - 2 <o, tgt>)
+ * y f32 [M,C] (C % 4 == 0, C <= 1024); out (f32 [M,C], optional) receives o; loss_sum is ONE f32
+ * accumulator the caller zeroes (the caller divides by the row count of all taps).
+ * Backward: d loss / d y for loss = loss_scale * sum_rows(2 - 2<o,tgt>)  (dout == NULL) or for an
+ * explicit upstream gradient dout (f32 [M,C]);  dy bf16 [M,C]; dgamma/dbeta as in layernorm_bwd.
+ * ------------------------------------------------------------------------------------ */
+int unite_decoder_tail_fwd(const float* y, const float* gamma, const float* beta, float eps,
+                           const float* tgt, float* out, float* loss_sum, int32_t M, int32_t C, void* stream);
+int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps,
+                           const float* tgt, float loss_scale, const float* dout,
+                           void* dy_bf16, float* dgamma, float* dbeta, int32_t accumulate,
+                           void* workspace, int32_t M, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused AdamW over ONE flat f32 parameter buffer (torch.optim.AdamW semantics,
+ * optim_factory.py:162-163), with per-chunk hyper-parameter groups (optim_factory.py:76-118):
+ *   p *= 1 - lr_g*wd_g ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr_g/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   g = grad * grad_scale
+ * chunk_group[c] (uint8) names the group of elements [c*1024, (c+1)*1024); lr/wd arrays are HOST
+ * arrays of n_groups (<= 64) values, passed by value into the launch.  param_bf16 (optional) gets the
+ * bf16 shadow copy the GEMMs read.  grad_scale_dev (optional, device f32[1]) multiplies the gradient
+ * (1/loss-scale or the clip coefficient); skip the step entirely if *found_inf_dev != 0 (optional).
+ * ------------------------------------------------------------------------------------ */
+int unite_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                     const uint8_t* chunk_group, int64_t n_elems,
+                     const float* lr, const float* weight_decay, int32_t n_groups,
+                     float beta1, float beta2, float eps, int32_t step,
+                     const float* grad_scale_dev, const int32_t* found_inf_dev, void* stream);
+
+/* f32 -> bf16 cast of a flat buffer (initial shadow copy of the weights). */
+int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* Global L2 norm of a flat f32 buffer (utils.py:631-643): norm_out[0] = ||g||_2; if max_norm > 0
+ * also writes clip_coef_out[0] = min(1, max_norm/(norm+1e-6)) (torch clip_grad_norm_).
+ * workspace >= unite_grad_norm_workspace(n) bytes. */
+size_t unite_grad_norm_workspace(int64_t n);
+int unite_grad_norm_flat(const float* grad, int64_t n, float max_norm, float* norm_out, float* clip_coef_out,
+                         void* workspace, void* stream);
+
+/* Token mean over the sequence (stage 2/3 pooling, modeling_finetune.py:376, run_stage3.py:333-338):
+ * out[b,:] = mean_n x[b,n,:]  (x f32 [B,N,D], out f32 [B,D]).  Backward: dx[b,n,:] (+)= dout[b,:]/N. */
+int unite_token_mean_fwd(const float* x, float* out, int32_t B, int32_t N, int32_t D, void* stream);
+int unite_token_mean_bwd(const float* dout, float* dx, int32_t accumulate, int32_t B, int32_t N, int32_t D, void* stream);
+
+/* Softmax cross-entropy with optional per-row weights (run_stage2.py:681, run_stage3.py:486,606-612):
+ * loss_sum += sum_i w_i * CE(logits[i,:], label[i]) over rows with label >= 0;  dlogits = scale * w_i *
+ * (softmax - onehot).  logits f32 [M,C], C <= 1024. */
+int unite_softmax_ce(const float* logits, const int64_t* labels, const float* row_weight, float grad_scale,
+                     float* loss_sum, float* dlogits, int32_t M, int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNITE_HIP_H */

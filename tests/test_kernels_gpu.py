@@ -1,0 +1,376 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point of libunite_hip.so against a plain PyTorch fp32 reference
+(or the oracle's helper where one exists) on the same inputs.  bf16 operands are rounded ONCE on the host, so
+what is compared is the kernel's arithmetic, not the rounding of its inputs.
+Tolerances: integer-valued GEMM data is bit exact; otherwise fp32-accumulate vs fp32 reference,
+|d| <= 2e-2 * scale for bf16 outputs (8 mantissa bits) and 1e-4 for f32 outputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import umt_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs a MI355X"
+    from unite_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 96), (8, 64, 8), (16, 24, 200), (520, 768, 768)])
+def test_gemm_exact_integers(ops, ta, tb, M, N, K):
+    """Small-integer operands: every product and partial sum is exact in f32 -> bit-exact vs f64 matmul.
+    Asymmetric random data catches swapped row/col maps and wrong k pairing in the transposing reads."""
+    if ta and M % 8:
+        pytest.skip("A^T rows must be 16-byte multiples")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    b = torch.randint(-4, 5, (N, K), generator=g).float()
+    ref = (a.double() @ b.double().t()).float()
+    a_d = bf(a.t().contiguous() if ta else a).to(DEV)
+    b_d = bf(b.t().contiguous() if tb else b).to(DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a_d, b_d, out, trans_a=ta, trans_b=tb)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 330, 264, 192
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    acc = a.float() @ w.float().t() + bias
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    # bias + GELU with saved pre-activation
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ad, wd, out, bias=bd, act=ops.ACT_GELU, aux_out=z)
+    torch.testing.assert_close(z.float().cpu(), acc, atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(out.float().cpu(), O.gelu_erf(acc), atol=2e-2, rtol=1e-2)
+    # QuickGELU
+    ops.gemm(ad, wd, out, bias=bd, act=ops.ACT_QUICKGELU)
+    torch.testing.assert_close(out.float().cpu(), O.quick_gelu(acc), atol=2e-2, rtol=1e-2)
+    # GELU' (backward of fc1): out = acc * gelu'(z)
+    zz = bf(rnd(M, N, seed=4))
+    zg = zz.float().clone().requires_grad_(True)
+    O.gelu_erf(zg).sum().backward()
+    outf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, outf, bias=bd, act=ops.ACT_DGELU, aux_in=zz.to(DEV))
+    torch.testing.assert_close(outf.cpu(), acc * zg.grad, atol=1e-4, rtol=1e-4)
+    # stochastic-depth row scale + residual (f32) + bf16 copy
+    res = rnd(M, N, seed=5)
+    rows_per = 33
+    rs = torch.tensor([0.0 if i % 3 == 0 else 1.0 / 0.9 for i in range(M // rows_per)])
+    cp = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ad, wd, outf, bias=bd, row_scale=rs.to(DEV), rows_per_scale=rows_per, residual=res.to(DEV), out_bf16_copy=cp)
+    ref = res + acc * rs.repeat_interleave(rows_per)[:, None]
+    torch.testing.assert_close(outf.cpu(), ref, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(cp.float().cpu(), ref, atol=3e-2, rtol=1e-2)
+    # accumulate into an f32 output (weight-gradient accumulation)
+    base = rnd(M, N, seed=6)
+    outf.copy_(base.to(DEV))
+    ops.gemm(ad, wd, outf, accumulate=True)
+    torch.testing.assert_close(outf.cpu(), base + (acc - bias), atol=1e-4, rtol=1e-4)
+    # strided views: A is a column slice of a wider matrix, out is a column slice
+    wide = bf(rnd(M, 3 * K, seed=7)).to(DEV)
+    big = torch.zeros(M, 2 * N, dtype=torch.float32, device=DEV)
+    ops.gemm(wide[:, K:2 * K], wd, big[:, N:])
+    torch.testing.assert_close(big[:, N:].cpu(), wide[:, K:2 * K].float().cpu() @ w.float().t(), atol=1e-4, rtol=1e-4)
+    assert float(big[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from unite_amd._lib import UniteHipError
+    a = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)      # K = 12: rows are not 16-byte multiples
+    b = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(UniteHipError):
+        ops.gemm(a, b, torch.empty(16, 16, dtype=torch.float32, device=DEV))
+    with pytest.raises(UniteHipError):
+        ops.gemm(torch.zeros(16, 16, dtype=torch.bfloat16), torch.zeros(16, 16, dtype=torch.bfloat16, device=DEV),
+                 torch.empty(16, 16, dtype=torch.float32, device=DEV))  # CPU tensor
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(7, 64), (130, 768), (33, 512), (5, 1024)])
+def test_layernorm_fwd_bwd(ops, M, D):
+    x = rnd(M, D, seed=1, scale=2.0) + 0.3
+    gam, bet = 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    xg, gg, bg = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y_ref = O.layer_norm(xg, gg, bg, 1e-6)
+    dy = bf(rnd(M, D, seed=4))
+    y_ref.backward(dy.float())
+    xd = x.to(DEV)
+    y = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    ops.layernorm_fwd(xd, gam.to(DEV), bet.to(DEV), 1e-6, y, mean=mean, rstd=rstd)
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), atol=2e-5, rtol=1e-5)
+    yb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    pa = rnd(M, D, seed=5)
+    ops.layernorm_fwd(xd, gam.to(DEV), bet.to(DEV), 1e-6, yb, post_add=pa.to(DEV))
+    torch.testing.assert_close(yb.float().cpu(), y_ref.detach() + pa, atol=3e-2, rtol=1e-2)
+    # gathered rows
+    idx = torch.tensor([M - 1, 0, M // 2], dtype=torch.int32)
+    yg = torch.empty(3, D, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(xd, gam.to(DEV), bet.to(DEV), 1e-6, yg, row_index=idx.to(DEV))
+    torch.testing.assert_close(yg.cpu(), y_ref.detach()[idx.long()], atol=2e-5, rtol=1e-5)
+    # backward
+    ws = torch.empty(ops.layernorm_bwd_workspace(M, D), dtype=torch.uint8, device=DEV)
+    dres = rnd(M, D, seed=6)
+    dx = torch.empty(M, D, device=DEV); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dgam = torch.empty(D, device=DEV); dbet = torch.empty(D, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.to(DEV), dx_residual=dres.to(DEV), dx_out=dx, dx_bf16=dxb,
+                      dgamma=dgam, dbeta=dbet, workspace=ws)
+    torch.testing.assert_close(dx.cpu(), xg.grad + dres, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dxb.float().cpu(), xg.grad + dres, atol=3e-2, rtol=1e-2)
+    torch.testing.assert_close(dgam.cpu(), gg.grad, atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(dbet.cpu(), bg.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_colsum(ops):
+    M, N = 1000, 776
+    x = bf(rnd(M, N, seed=1))
+    out = torch.empty(N, device=DEV)
+    ws = torch.empty(ops.colsum_workspace(M, N), dtype=torch.uint8, device=DEV)
+    ops.colsum(x.to(DEV), out, ws)
+    torch.testing.assert_close(out.cpu(), x.float().sum(0), atol=1e-3, rtol=1e-4)
+    wide = bf(rnd(M, 3 * 256, seed=2)).to(DEV)
+    ops.colsum(wide[:, 512:], out[:256], ws, accumulate=False)
+    torch.testing.assert_close(out[:256].cpu(), wide[:, 512:].float().sum(0).cpu(), atol=1e-3, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, N, H):
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 64 ** -0.5) @ k.transpose(-2, -1)
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, H * 64)
+    return o, torch.logsumexp(s, -1), p
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 4, 2), (3, 5, 2), (2, 32, 1), (2, 197, 3), (2, 320, 2), (1, 33, 12), (1, 224, 1)])
+def test_attention_fwd_bwd(ops, B, N, H):
+    qkv = bf(rnd(B * N, 3 * H * 64, seed=N, scale=1.0))
+    qkv_g = qkv.float().clone().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(qkv_g, B, N, H)
+    do = bf(rnd(B * N, H * 64, seed=N + 1))
+    o_ref.backward(do.float())
+    qd = qkv.to(DEV)
+    out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qd, out, lse, B, N, H, 64 ** -0.5)
+    torch.testing.assert_close(out.float().cpu(), o_ref.detach(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), atol=2e-3, rtol=1e-4)
+    dqkv = torch.full((B * N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    ops.attn_bwd(qd, out, do.to(DEV), lse, delta, dqkv, B, N, H, 64 ** -0.5)
+    g = qkv_g.grad
+    err = (dqkv.float().cpu() - g).abs().max().item()
+    assert err <= 3e-2 * max(1.0, g.abs().max().item()), err
+    # relative L2 per q/k/v block
+    for i, name in enumerate("qkv"):
+        a = dqkv.float().cpu()[:, i * H * 64:(i + 1) * H * 64]
+        r = g[:, i * H * 64:(i + 1) * H * 64]
+        assert (a - r).norm() <= 2e-2 * r.norm() + 1e-6, name
+
+
+def test_attention_softmax_spike(ops):
+    """One key dominates one query (large logit): exercises the exact full-row softmax with a huge max."""
+    B, N, H = 1, 320, 1
+    qkv = rnd(B * N, 192, seed=3, scale=0.5)
+    qkv[7, :64] = 6.0
+    qkv[300, 64:128] = 6.0            # q7 . k300 = 64*36*0.125 = 288
+    qkv = bf(qkv)
+    o_ref, lse_ref, p = _attn_ref(qkv, B, N, H)
+    out = torch.empty(B * N, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qkv.to(DEV), out, lse, B, N, H, 64 ** -0.5)
+    assert p[0, 0, 7, 300] > 0.999
+    torch.testing.assert_close(out.float().cpu(), o_ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
+
+
+def test_attn_cls_probs(ops):
+    B, N, H = 5, 197, 12
+    qkv = bf(rnd(B * N, 3 * H * 64, seed=9))
+    _, _, p = _attn_ref(qkv, B, N, H)
+    ref = p.mean(1)[:, 0, 1:]
+    probs = torch.empty(B, N - 1, device=DEV)
+    ops.attn_cls_probs(qkv.to(DEV), probs, B, N, H, 64 ** -0.5)
+    torch.testing.assert_close(probs.cpu(), ref, atol=1e-6, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ gathers
+def test_im2col_and_gather_rows(ops):
+    B, T, H, W, P = 2, 3, 64, 48, 16
+    vid = rnd(B, 3, T, H, W, seed=1)
+    ref = bf(O.im2col(vid, P, 1)).reshape(-1, 3 * P * P)
+    n_tok = ref.shape[0]
+    cols = torch.empty(n_tok, 3 * P * P, dtype=torch.bfloat16, device=DEV)
+    ops.im2col_gather(vid.to(DEV), None, cols, P)
+    assert torch.equal(cols.cpu(), ref)
+    idx = torch.tensor([n_tok - 1, 0, 17, 5, 40], dtype=torch.int32)
+    cg = torch.empty(5, 3 * P * P, dtype=torch.bfloat16, device=DEV)
+    ops.im2col_gather(vid.to(DEV), idx.to(DEV), cg, P)
+    assert torch.equal(cg.cpu(), ref[idx.long()])
+    table = rnd(36, 128, seed=2)
+    out = torch.empty(5, 128, device=DEV)
+    ops.gather_rows(table.to(DEV), idx.to(DEV), out, modulo=36)
+    assert torch.equal(out.cpu(), table[idx.long() % 36])
+
+
+def test_clip_embed_ln_and_l2(ops):
+    BT, HW, D = 3, 196, 768
+    patches = bf(rnd(BT * HW, D, seed=1))
+    cls, pos = rnd(D, seed=2), rnd(HW + 1, D, seed=3)
+    gam, bet = 1 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5)
+    x = torch.cat([cls.expand(BT, 1, D), patches.float().reshape(BT, HW, D)], 1) + pos
+    ref = O.layer_norm(x, gam, bet, 1e-5).reshape(-1, D)
+    out = torch.empty(BT * (HW + 1), D, device=DEV)
+    ops.clip_embed_ln(patches.to(DEV), cls.to(DEV), pos.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, out, BT, HW, D)
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+    y = rnd(77, 512, seed=6)
+    yd = y.to(DEV)
+    ops.l2_normalize_rows(yd)
+    torch.testing.assert_close(yd.cpu(), y / y.norm(dim=-1, keepdim=True), atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ masks
+def test_mask_from_importance_matches_reference_rule(ops):
+    from oracle.filler import make_importance
+    B, T, N, n_vis = 3, 8, 196, 40
+    imp = make_importance(B * T, N, seed=5)
+    ref = O.mask_from_importance(imp, n_vis, B)
+    mask = torch.empty(B * T * N, dtype=torch.uint8, device=DEV)
+    vis = torch.empty(B * T * n_vis, dtype=torch.int32, device=DEV)
+    ops.mask_from_importance(imp.to(DEV), mask, vis, n_vis)
+    assert torch.equal(mask.cpu().bool().view(B, -1), ref)
+    assert torch.equal(vis.cpu().long(), (~ref).view(-1).nonzero().flatten())     # row order of x[~mask]
+
+
+def test_mask_sample_properties_and_distribution(ops):
+    BT, N, n_vis = 4096, 196, 40
+    w = torch.rand(N, generator=torch.Generator().manual_seed(1)) ** 3 + 1e-3
+    w = (w / w.sum()).repeat(BT, 1)
+    mask = torch.empty(BT * N, dtype=torch.uint8, device=DEV)
+    vis = torch.empty(BT * n_vis, dtype=torch.int32, device=DEV)
+    ops.mask_sample(w.to(DEV), 1234, mask, vis, n_vis)
+    m = mask.cpu().view(BT, N).bool()
+    assert ((~m).sum(1) == n_vis).all()                      # exactly n_vis visible per frame (run_stage1.py:380-386)
+    v = vis.cpu().view(BT, n_vis).long()
+    assert (v[:, 1:] > v[:, :-1]).all()                      # ascending
+    assert torch.equal((v - torch.arange(BT)[:, None] * N), (~m).nonzero()[:, 1].view(BT, n_vis))
+    # inclusion frequencies vs torch.multinomial without replacement (the reference's sampler)
+    ref = torch.multinomial(w, N, generator=torch.Generator().manual_seed(2))[:, :n_vis]
+    f_ref = torch.zeros(N).scatter_add_(0, ref.flatten(), torch.ones(ref.numel())) / BT
+    f_gpu = (~m).float().mean(0)
+    assert (f_ref - f_gpu).abs().max() < 0.04, (f_ref - f_gpu).abs().max()
+    # a different seed gives a different draw, the same seed the same draw
+    mask2 = torch.empty_like(mask); vis2 = torch.empty_like(vis)
+    ops.mask_sample(w.to(DEV), 1234, mask2, vis2, n_vis)
+    assert torch.equal(mask, mask2)
+    ops.mask_sample(w.to(DEV), 99, mask2, vis2, n_vis)
+    assert not torch.equal(mask, mask2)
+
+
+# ------------------------------------------------------------------------------------ decoder tail + loss
+@pytest.mark.parametrize("M,Cd", [(9, 32), (70, 512)])
+def test_decoder_tail(ops, M, Cd):
+    y = rnd(M, Cd, seed=1, scale=1.5)
+    gam, bet = 1 + 0.2 * rnd(Cd, seed=2), 0.1 * rnd(Cd, seed=3)
+    tgt = rnd(M, Cd, seed=4); tgt = tgt / tgt.norm(dim=-1, keepdim=True)
+    yg, gg, bg = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    u = O.layer_norm(yg, gg, bg, 1e-6)
+    o = u / u.norm(dim=-1, keepdim=True)
+    loss_sum = (2 - 2 * (o * tgt).sum(-1)).sum()
+    scale = 1.0 / (3 * M)
+    (loss_sum * scale).backward()
+    yd, gd, bd, td = y.to(DEV), gam.to(DEV), bet.to(DEV), tgt.to(DEV)
+    out = torch.empty(M, Cd, device=DEV); ls = torch.zeros(1, device=DEV)
+    ops.decoder_tail_fwd(yd, gd, bd, 1e-6, td, out, ls)
+    torch.testing.assert_close(out.cpu(), o.detach(), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(ls.cpu()[0], loss_sum.detach(), atol=1e-3, rtol=1e-5)
+    ws = torch.empty(ops.layernorm_bwd_workspace(M, Cd), dtype=torch.uint8, device=DEV)
+    dy = torch.empty(M, Cd, dtype=torch.bfloat16, device=DEV); dg = torch.empty(Cd, device=DEV); db = torch.empty(Cd, device=DEV)
+    ops.decoder_tail_bwd(yd, gd, bd, 1e-6, td, scale, None, dy, dg, db, ws)
+    assert (dy.float().cpu() - yg.grad).abs().max() <= 1e-2 * yg.grad.abs().max() + 1e-8
+    torch.testing.assert_close(dg.cpu(), gg.grad, atol=1e-5, rtol=1e-3)
+    torch.testing.assert_close(db.cpu(), bg.grad, atol=1e-5, rtol=1e-3)
+    # explicit upstream gradient
+    do = rnd(M, Cd, seed=5)
+    yg.grad = None; gg.grad = None; bg.grad = None
+    u = O.layer_norm(yg, gg, bg, 1e-6); (u / u.norm(dim=-1, keepdim=True)).backward(do)
+    ops.decoder_tail_bwd(yd, gd, bd, 1e-6, None, 0.0, do.to(DEV), dy, dg, db, ws)
+    assert (dy.float().cpu() - yg.grad).abs().max() <= 1e-2 * yg.grad.abs().max() + 1e-8
+    torch.testing.assert_close(dg.cpu(), gg.grad, atol=1e-4, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def test_adamw_and_grad_norm(ops):
+    n = 5 * 1024 + 512 + 3 * 1024
+    p0 = rnd(n, seed=1)
+    groups = torch.zeros((n + 1023) // 1024, dtype=torch.uint8)
+    groups[5:] = 1                                   # elements >= 5120 -> group 1 (no decay)
+    lrs, wds = [1e-3, 2e-3], [0.05, 0.0]
+    pa, pb = p0[:5120].clone().requires_grad_(True), p0[5120:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pa], "lr": lrs[0], "weight_decay": wds[0]},
+                             {"params": [pb], "lr": lrs[1], "weight_decay": wds[1]}], betas=(0.9, 0.95), eps=1e-8)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    pbf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(ops.grad_norm_workspace(n), dtype=torch.uint8, device=DEV)
+    norm = torch.empty(1, device=DEV); coef = torch.empty(1, device=DEV)
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step)
+        pa.grad, pb.grad = g[:5120].clone(), g[5120:].clone()
+        opt.step()
+        gd = g.to(DEV)
+        ops.grad_norm_flat(gd, norm, ws, max_norm=0.5, clip_coef_out=coef)
+        torch.testing.assert_close(norm.cpu()[0], g.norm(), rtol=1e-5, atol=0)
+        torch.testing.assert_close(coef.cpu()[0], torch.clamp(0.5 / (g.norm() + 1e-6), max=1.0), rtol=1e-5, atol=0)
+        ops.adamw_flat(p, gd, m, v, pbf, groups.to(DEV), lrs, wds, 0.9, 0.95, 1e-8, step)
+    ref = torch.cat([pa.detach(), pb.detach()])
+    torch.testing.assert_close(p.cpu(), ref, atol=2e-6, rtol=1e-5)
+    assert torch.equal(pbf.cpu(), p.cpu().to(torch.bfloat16))
+    # gradient scale from a device scalar (clip coefficient)
+    p2 = p0.clone().to(DEV); m.zero_(); v.zero_()
+    half = torch.tensor([0.5], device=DEV)
+    ops.adamw_flat(p2, gd, m, v, None, groups.to(DEV), lrs, wds, 0.9, 0.95, 1e-8, 1, grad_scale=half)
+    torch.testing.assert_close(m.cpu(), 0.1 * 0.5 * g, atol=1e-7, rtol=1e-5)
+
+
+def test_token_mean_and_softmax_ce(ops):
+    B, N, D = 3, 50, 768
+    x = rnd(B, N, D, seed=1)
+    out = torch.empty(B, D, device=DEV)
+    ops.token_mean_fwd(x.to(DEV), out)
+    torch.testing.assert_close(out.cpu(), x.mean(1), atol=1e-5, rtol=1e-5)
+    dout = rnd(B, D, seed=2)
+    dx = torch.empty(B, N, D, device=DEV)
+    ops.token_mean_bwd(dout.to(DEV), dx)
+    torch.testing.assert_close(dx.cpu(), (dout / N)[:, None, :].expand(B, N, D), atol=1e-7, rtol=1e-5)
+    M, Cc = 11, 8
+    logits = rnd(M, Cc, seed=3, scale=2.0).requires_grad_(True)
+    labels = torch.randint(0, Cc, (M,), generator=torch.Generator().manual_seed(4))
+    w = torch.rand(M, generator=torch.Generator().manual_seed(5))
+    ce = (torch.nn.functional.cross_entropy(logits, labels, reduction="none") * w).sum()
+    (ce * 0.25).backward()
+    ls = torch.zeros(1, device=DEV); dl = torch.empty(M, Cc, device=DEV)
+    ops.softmax_ce(logits.detach().to(DEV), labels.to(DEV), ls, dl, row_weight=w.to(DEV), grad_scale=0.25)
+    torch.testing.assert_close(ls.cpu()[0], ce.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(dl.cpu(), logits.grad, atol=1e-6, rtol=1e-4)

@@ -1,0 +1,103 @@
+"""ctypes binding of libunite_hip.so (the C ABI declared in include/unite_hip.h).
+
+The library is built in-tree by ``make -C unite_amd/csrc`` (or ``__graft_entry__.build()``) into
+``unite_amd/lib/libunite_hip.so``.  There is NO fallback: if the library is missing the import of any
+op raises, so a GPU box can never silently run something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunite_hip.so")
+
+c_p = C.c_void_p
+c_i = C.c_int32
+c_f = C.c_float
+c_sz = C.c_size_t
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+
+
+class GemmArgs(C.Structure):
+    """struct unite_gemm_args (include/unite_hip.h)."""
+    _fields_ = [
+        ("M", c_i), ("N", c_i), ("K", c_i),
+        ("trans_a", c_i), ("trans_b", c_i),
+        ("A", c_p), ("lda", c_i),
+        ("B", c_p), ("ldb", c_i),
+        ("bias", c_p),
+        ("act", c_i),
+        ("aux_in", c_p), ("ld_aux_in", c_i),
+        ("aux_out", c_p), ("ld_aux_out", c_i),
+        ("row_scale", c_p), ("rows_per_scale", c_i),
+        ("residual", c_p), ("ldr", c_i),
+        ("out", c_p), ("ldc", c_i), ("out_f32", c_i), ("accumulate", c_i),
+        ("out_bf16_copy", c_p), ("ld_copy", c_i),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/unite_hip.h one to one
+SIGNATURES = {
+    "unite_abi_version": (c_i, []),
+    "unite_target_arch": (C.c_char_p, []),
+    "unite_gemm_bf16": (c_i, [C.POINTER(GemmArgs), c_p]),
+    "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
+    "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_colsum_workspace": (c_sz, [c_i, c_i]),
+    "unite_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "unite_attn_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "unite_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "unite_attn_cls_probs": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "unite_im2col_gather": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "unite_gather_rows_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_clip_embed_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "unite_l2_normalize_rows": (c_i, [c_p, c_i, c_i, c_p]),
+    "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_decoder_tail_fwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_adamw_flat": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
+    "unite_cast_f32_bf16": (c_i, [c_p, c_p, c_i64, c_p]),
+    "unite_grad_norm_workspace": (c_sz, [c_i64]),
+    "unite_grad_norm_flat": (c_i, [c_p, c_i64, c_f, c_p, c_p, c_p, c_p]),
+    "unite_token_mean_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_token_mean_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "unite_softmax_ce": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class UniteHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libunite_hip.so and bind every symbol of the header; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UniteHipError(
+            f"{LIB_PATH} not found: build it with `make -C unite_amd/csrc` (or __graft_entry__.build()). "
+            "unite_amd has no CPU / eager fallback for its device ops.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.unite_abi_version() != 1:
+        raise UniteHipError("libunite_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        kind = {-1: "UNITE_EINVAL (bad shape/alignment/null pointer)", -2: "UNITE_ENOSUP (unsupported shape)"}.get(
+            code, f"hipError_t {code}")
+        raise UniteHipError(f"{what} failed: {kind}")

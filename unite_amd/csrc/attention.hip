@@ -1,0 +1,351 @@
+// Fused multi-head self-attention (forward + backward) for short sequences on gfx950: head_dim 64, N <= 320 keys,
+// i.e. the 320 visible student tokens and the 197 teacher tokens of UNITE stage 1.  A whole head's K and V
+// (<= 40 KiB each) live in LDS, so the softmax is exact over the full row held in MFMA accumulators: no online
+// rescaling, no N x N matrix in HBM.
+//
+// MFMA orientation (v_mfma_f32_16x16x32_bf16):  S^T = K Q^T puts the key index on the accumulator ROWS and the
+// query on the LANES, so (a) row statistics are per-lane scalars + two cross-lane shuffles, and (b) the bf16-packed
+// accumulators ARE the B operand of the next product (O^T = V^T P^T, dQ^T = K^T dS^T) with no LDS round trip:
+// element j of lane group G is key 4G+j of the first 16-key tile (j<4) / of the second (j>=4), and the other operand
+// is fetched with the same k order by two ds_read_b64_tr_b16 transposing reads.  The backward recomputes P from
+// (Q, K, LSE): one kernel per query block for dQ (also emits delta = rowsum(dO*O)), one per key block for dK, dV
+// (key on the lanes there, so P and dS are again operands as they stand).
+//
+// One LDS image serves row reads (ds_read_b128) and transposed reads: 128-B rows, 32-B chunk c of row r stored at
+// chunk c ^ ((r>>1)&3); conflict-free for both access kinds.  Tiles are staged by LDS-DMA with the swizzle on the
+// source address; rows >= N read as zero through the buffer descriptor's range check.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int row_addr(int row, int c16) {   // byte offset of 16-B chunk c16 of `row`
+    return row * 128 + (((((c16 >> 1) ^ ((row >> 1) & 3)) << 1) | (c16 & 1)) << 4);
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, int lane) {
+    return *(const bf16x8*)(tile + row_addr(row0 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// transposed fragment: element j = X[rows32 + (j<4 ? 4G+j : 16+4G+j-4)][16 dt + (l&15)]
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rows32, int dt, int lane) {
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r_lo = rows32 + 4 * G + q, r_hi = r_lo + 16;
+    const s16x4 lo = lds_read_tr16(tile + r_lo * 128 + ((dt ^ ((r_lo >> 1) & 3)) << 5) + 8 * p);
+    const s16x4 hi = lds_read_tr16(tile + r_hi * 128 + ((dt ^ ((r_hi >> 1) & 3)) << 5) + 8 * p);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
+    u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+// stage rows [0, rows_padded) of one head slice (element offset base, row stride ld) into the swizzled image
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int rows_padded, int n_valid, uint32_t base, int ld,
+                                           int wave, int nwaves, int lane) {
+    for (int it = wave; it < rows_padded / 8; it += nwaves) {
+        const int r = it * 8 + (lane >> 3), p = lane & 7;
+        const int lc16 = ((((p >> 1) ^ ((r >> 1) & 3)) << 1) | (p & 1));
+        const uint32_t voff = (r < n_valid) ? (base + (uint32_t)r * ld + lc16 * 8) * 2u : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(tile + it * 1024), 16, voff, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ void store_bf16x4(uint16_t* p, f32x4 v, float s) {
+    *(u32x2*)p = (u32x2){pack_bf16x2(v[0] * s, v[1] * s), pack_bf16x2(v[2] * s, v[3] * s)};
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int NT16>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
+                                                          int N, int H, float scale, uint32_t qkv_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = NT16 * 16;
+    char* Ks = smem;
+    char* Vs = smem + NK * 128;
+    const int lane = threadIdx.x & 63, G = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H, HD = H * 64, ld = 3 * HD;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)qkv_bytes, 0x00020000);
+    const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
+    stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
+    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float sl2 = scale * LOG2E;
+    const int nqt = (N + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + c, qc = min(q, N - 1);
+        const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
+        const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+        f32x4 st[NT16];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT16; ++kt) {
+            f32x4 s = mfma16(row_frag(Ks, kt * 16, 0, lane), qf0, (f32x4){0.f, 0.f, 0.f, 0.f});
+            s = mfma16(row_frag(Ks, kt * 16, 1, lane), qf1, s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * G + r >= N) s[r] = -INFINITY;
+                m = fmaxf(m, s[r]);
+            }
+            st[kt] = s;
+        }
+        m = group_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f((st[kt][r] - m) * sl2);
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum = group_sum(sum);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT16 / 2; ++kk) {
+            const bf16x8 pf = pack_pair(st[2 * kk], st[2 * kk + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(Vs, kk * 32, dt, lane), pf, o[dt]);   // O^T[d][q]
+        }
+        if (q < N) {
+            const float inv = 1.0f / sum;
+            uint16_t* op = out + (size_t)(b * N + q) * HD + h * 64 + 4 * G;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store_bf16x4(op + dt * 16, o[dt], inv);
+            if (G == 0) lse[((size_t)b * H + h) * N + q] = m * scale + __logf(sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: dQ (+ delta)
+template <int NT16>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                             const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, float scale,
+                                                             uint32_t qkv_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = NT16 * 16;
+    char* Ks = smem;
+    char* Vs = smem + NK * 128;
+    const int lane = threadIdx.x & 63, G = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H, HD = H * 64, ld = 3 * HD;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)qkv_bytes, 0x00020000);
+    const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
+    stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
+    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float sl2 = scale * LOG2E;
+    const int nqt = (N + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + c, qc = min(q, N - 1);
+        const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
+        const uint16_t* dop = dout + (size_t)(b * N + qc) * HD + h * 64 + 8 * G;
+        const uint16_t* oop = out + (size_t)(b * N + qc) * HD + h * 64 + 8 * G;
+        const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+        const bf16x8 df0 = *(const bf16x8*)dop, df1 = *(const bf16x8*)(dop + 32);
+        const bf16x8 of0 = *(const bf16x8*)oop, of1 = *(const bf16x8*)(oop + 32);
+        float dl = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
+        dl = group_sum(dl);
+        const float l2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+        if (q < N && G == 0) delta[((size_t)b * H + h) * N + q] = dl;
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT16 / 2; ++kk) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * kk + t;
+                f32x4 s = mfma16(row_frag(Ks, kt * 16, 0, lane), qf0, (f32x4){0.f, 0.f, 0.f, 0.f});
+                s = mfma16(row_frag(Ks, kt * 16, 1, lane), qf1, s);
+                f32x4 dp = mfma16(row_frag(Vs, kt * 16, 0, lane), df0, (f32x4){0.f, 0.f, 0.f, 0.f});
+                dp = mfma16(row_frag(Vs, kt * 16, 1, lane), df1, dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (kt * 16 + 4 * G + r < N) ? exp2f(s[r] * sl2 - l2) : 0.f;
+                    ds[t][r] = p * (dp[r] - dl);
+                }
+            }
+            const bf16x8 dsf = pack_pair(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag(Ks, kk * 32, dt, lane), dsf, dq[dt]);   // dQ^T[d][q]
+        }
+        if (q < N) {
+            uint16_t* op = dqkv + (size_t)(b * N + q) * ld + h * 64 + 4 * G;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store_bf16x4(op + dt * 16, dq[dt], scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: dK, dV
+// 8 waves; wave w owns key tiles [w*KTW, (w+1)*KTW); Q and dO of the head live in LDS; loop over 32-query steps.
+template <int NT16, int KTW>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              uint16_t* __restrict__ dqkv, int N, int H, float scale, uint32_t qkv_bytes,
+                                                              uint32_t dout_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NQ = NT16 * 16;
+    char* Qs = smem;
+    char* Ds = smem + NQ * 128;
+    float* lse_s = (float*)(smem + 2 * NQ * 128);
+    float* dl_s = lse_s + NQ;
+    const int lane = threadIdx.x & 63, G = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H, HD = H * 64, ld = 3 * HD;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)qkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)dout_bytes, 0x00020000);
+    stage_rows(rs, Qs, NQ, N, (uint32_t)(b * N) * ld + h * 64, ld, wave, 8, lane);
+    stage_rows(rsd, Ds, NQ, N, (uint32_t)(b * N) * HD + h * 64, HD, wave, 8, lane);
+    for (int i = threadIdx.x; i < NQ; i += 512) {
+        lse_s[i] = (i < N) ? lse[((size_t)b * H + h) * N + i] * LOG2E : 0.f;
+        dl_s[i] = (i < N) ? delta[((size_t)b * H + h) * N + i] : 0.f;
+    }
+    // this wave's K / V fragments (B-operand layout: key on the lane)
+    bf16x8 kf[KTW][2], vf[KTW][2];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+        const int key = (wave * KTW + i) * 16 + c, kc = min(key, N - 1);
+        const uint16_t* kp = qkv + (size_t)(b * N + kc) * ld + HD + h * 64 + 8 * G;
+        kf[i][0] = *(const bf16x8*)kp;
+        kf[i][1] = *(const bf16x8*)(kp + 32);
+        vf[i][0] = *(const bf16x8*)(kp + HD);
+        vf[i][1] = *(const bf16x8*)(kp + HD + 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 dk[KTW][4], dv[KTW][4];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[i][dt] = dv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float sl2 = scale * LOG2E;
+
+    for (int kq = 0; kq < NQ / 32; ++kq) {
+        f32x4 P[2][KTW], dS[2][KTW];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q0 = kq * 32 + t * 16;
+            const bf16x8 qa0 = row_frag(Qs, q0, 0, lane), qa1 = row_frag(Qs, q0, 1, lane);
+            const bf16x8 da0 = row_frag(Ds, q0, 0, lane), da1 = row_frag(Ds, q0, 1, lane);
+            const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 4 * G), d4 = *(const f32x4*)(dl_s + q0 + 4 * G);
+#pragma unroll
+            for (int i = 0; i < KTW; ++i) {
+                f32x4 s = mfma16(qa0, kf[i][0], (f32x4){0.f, 0.f, 0.f, 0.f});     // S[q][key]
+                s = mfma16(qa1, kf[i][1], s);
+                f32x4 dp = mfma16(da0, vf[i][0], (f32x4){0.f, 0.f, 0.f, 0.f});    // dP[q][key]
+                dp = mfma16(da1, vf[i][1], dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (q0 + 4 * G + r < N) ? exp2f(s[r] * sl2 - l4[r]) : 0.f;
+                    P[t][i][r] = p;
+                    dS[t][i][r] = p * (dp[r] - d4[r]);
+                }
+            }
+        }
+        bf16x8 dot[4], qtr[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dot[dt] = tr_frag(Ds, kq * 32, dt, lane);    // dO^T[d][q]
+            qtr[dt] = tr_frag(Qs, kq * 32, dt, lane);    // Q^T[d][q]
+        }
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+            const bf16x8 pf = pack_pair(P[0][i], P[1][i]), dsf = pack_pair(dS[0][i], dS[1][i]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[i][dt] = mfma16(dot[dt], pf, dv[i][dt]);     // dV^T[d][key]
+                dk[i][dt] = mfma16(qtr[dt], dsf, dk[i][dt]);    // dK^T[d][key]
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+        const int key = (wave * KTW + i) * 16 + c;
+        if (key < N) {
+            uint16_t* kp = dqkv + (size_t)(b * N + key) * ld + HD + h * 64 + 4 * G;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store_bf16x4(kp + dt * 16, dk[i][dt], scale);
+                store_bf16x4(kp + HD + dt * 16, dv[i][dt], 1.0f);
+            }
+        }
+    }
+}
+
+inline int nt16_for(int N) { return N <= 32 ? 2 : (N <= 224 ? 14 : (N <= 320 ? 20 : 0)); }
+
+// dynamic LDS above 64 KiB has to be opted into once per kernel
+template <auto Kern>
+inline int set_lds(int bytes) {
+    static int granted = 0;
+    if (bytes > 64 * 1024 && bytes > granted) {
+        hipError_t e = hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        granted = bytes;
+    }
+    return 0;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(NT, ...)                                                                     \
+    switch (NT) {                                                                                  \
+        case 2: { constexpr int NT16 = 2; constexpr int KTW = 1; (void)KTW; __VA_ARGS__; } break;   \
+        case 14: { constexpr int NT16 = 14; constexpr int KTW = 2; (void)KTW; __VA_ARGS__; } break; \
+        default: { constexpr int NT16 = 20; constexpr int KTW = 3; (void)KTW; __VA_ARGS__; } break; \
+    }
+
+extern "C" int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
+    if (!qkv || !out || !lse || B <= 0 || N <= 0 || H <= 0) return UNITE_EINVAL;
+    const int nt = nt16_for(N);
+    if (!nt) return UNITE_ENOSUP;
+    const int64_t bytes = (int64_t)B * N * 3 * H * 64 * 2;
+    if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
+    const int lds = nt * 16 * 128 * 2;
+    ATTN_DISPATCH(nt, {
+        int e = set_lds<attn_fwd_kernel<NT16>>(lds);
+        if (e) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<NT16>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, lse,
+                           N, H, scale, (uint32_t)bytes);
+    });
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
+                              int32_t N, int32_t H, float scale, void* stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0) return UNITE_EINVAL;
+    const int nt = nt16_for(N);
+    if (!nt) return UNITE_ENOSUP;
+    const int64_t bytes = (int64_t)B * N * 3 * H * 64 * 2;
+    if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
+    const int lds = nt * 16 * 128 * 2;
+    const int lds2 = lds + nt * 16 * 4 * 2;
+    ATTN_DISPATCH(nt, {
+        int e = set_lds<attn_bwd_dq_kernel<NT16>>(lds);
+        if (e) return e;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NT16>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                           (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, N, H, scale, (uint32_t)bytes);
+        UNITE_LAUNCH_CHECK();
+        e = set_lds<attn_bwd_dkv_kernel<NT16, KTW>>(lds2);
+        if (e) return e;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NT16, KTW>), dim3(B * H), dim3(512), lds2, (hipStream_t)stream, (const uint16_t*)qkv,
+                           (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, N, H, scale, (uint32_t)bytes, (uint32_t)(bytes / 3));
+    });
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16, LDS-DMA staging).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "unite_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_AS __attribute__((address_space(3)))
+#define OOB_OFFSET 0x80000000u     // beyond any buffer we accept (< 2 GiB): buffer loads return 0
+
+#define UNITE_LAUNCH_CHECK()                     \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    // hipcc lowers the cast to v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+// 16x16x32 bf16 MFMA: A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], C[row 4(l>>4)+r][col l&15]
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4x16 block of 16-bit elements; lane i receives column i of the four rows (row q in element q).
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p);
+}

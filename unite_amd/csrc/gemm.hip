@@ -1,0 +1,245 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   out[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
+//
+// One 256-thread workgroup (4 waves as 2x2) computes a 128x128 tile; each wave owns 64x64 =
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  Operand tiles (128 x 64 k) are staged HBM -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction) into a double buffer; out-of-range
+// rows / k are handled by the buffer descriptor's range check (they read as zero), so every shape
+// with 16-byte rows is legal.  Both operand layouts are supported without a transposed copy in HBM:
+//   * k-contiguous operand ([rows][k], 128-B LDS rows, XOR-swizzled 16-B chunks, ds_read_b128)
+//   * k-strided operand   ([k][cols], 256-B LDS rows, swizzled, ds_read_b64_tr_b16 transposing reads)
+// so forward (x W^T), dgrad (dy W) and wgrad (dy^T x) all run on this one kernel.
+// The LDS image is lane-linear (LDS-DMA cannot scatter), so the swizzle is applied to the per-lane
+// SOURCE address and again on the read (cdna_hip_programming.md rule 21).
+// The accumulators leave through LDS so that the epilogue (bias, GELU / QuickGELU / GELU', stochastic-depth
+// row scale, residual add, bf16 + f32 outputs) reads and writes 16 B (bf16) / 32 B (f32) per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile (both layouts)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int CS_LD = 132;                       // f32 row stride of the epilogue image (conflict-free writes)
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 64 KiB  (epilogue image: 64 x 132 x 4 = 33 KiB, reuses it)
+
+struct Params {
+    unite_gemm_args a;
+    uint32_t a_bytes, b_bytes;
+};
+
+__device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// Stage one 128 x 64 operand tile.  TR == false: memory is [rows][k] (ld elements per row);
+// TR == true: memory is [k][rows].  `r0` = first row (m or n) of the tile, `k0` = first k.
+template <bool TR>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int r0, int k0, int R, int K,
+                                           int ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int it = wave * 4 + i;             // 16 wave-instructions of 1 KiB cover the tile
+        uint32_t voff;
+        if (!TR) {
+            const int r = it * 8 + (lane >> 3);  // tile row; 8 rows x 128 B per instruction
+            const int lc = (lane & 7) ^ (r & 7); // logical 16-B chunk this lane's LDS slot must hold
+            const int gr = r0 + r, gk = k0 + lc * 8;
+            voff = (gr < R && gk < K) ? (uint32_t)(gr * ld + gk) * 2u : OOB_OFFSET;
+        } else {
+            const int kr = it * 4 + (lane >> 4); // tile k-row; 4 rows x 256 B per instruction
+            const int lc = (lane & 15) ^ swz256(kr);
+            const int gk = k0 + kr, gr = r0 + lc * 8;
+            voff = (gk < K && gr < R) ? (uint32_t)(gk * ld + gr) * 2u : OOB_OFFSET;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + it * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+// Fragment of a 16-row block for k-step `ks` (32 k): element j = X[row0 + (l&15)][32 ks + 8 (l>>4) + j].
+template <bool TR>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int ks, int lane) {
+    if (!TR) {
+        const int row = row0 + (lane & 15);
+        const int lc = ks * 4 + (lane >> 4);
+        return *(const bf16x8*)(lds_tile + row * 128 + ((lc ^ (row & 7)) << 4));
+    } else {
+        const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int ch = (row0 >> 3) + (p >> 1);
+        const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
+        const s16x4 lo = lds_read_tr16(lds_tile + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (p & 1));
+        const s16x4 hi = lds_read_tr16(lds_tile + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (p & 1));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unite_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2) -> give each XCD a contiguous
+    // range of tiles, N fastest, so the A row panel and the whole B operand stay L2-resident.
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nb = nbm * nbn;
+    const int bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)p.b_bytes, 0x00020000);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    stage_tile<TA>(rsA, smem, m0, 0, g.M, g.K, g.lda, wave, lane);
+    stage_tile<TB>(rsB, smem + TILE_BYTES, n0, 0, g.N, g.K, g.ldb, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        char* cur = smem + (t & 1) * STAGE_BYTES;
+        char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+        if (t + 1 < nk) {
+            stage_tile<TA>(rsA, nxt, m0, (t + 1) * BK, g.M, g.K, g.lda, wave, lane);
+            stage_tile<TB>(rsB, nxt + TILE_BYTES, n0, (t + 1) * BK, g.N, g.K, g.ldb, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = load_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = load_frag<TB>(cur + TILE_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA of tile t+1 has landed
+        __syncthreads();                                   // ... for every wave; reads of tile t retired
+    }
+
+    // ---- epilogue: accumulators -> LDS (64 rows at a time) -> coalesced stores
+    float* cs = (float*)smem;
+    const int G = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(i * 16 + 4 * G + r) * CS_LD + wn * 64 + j * 16 + c16] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int lr = pass * 16 + (tid >> 4);
+            const int col = (tid & 15) * 8;
+            const int gm = m0 + half * 64 + lr, gn = n0 + col;
+            if (gm < g.M && gn < g.N) {
+                float v[8];
+                const f32x4 v0 = *(const f32x4*)(cs + lr * CS_LD + col);
+                const f32x4 v1 = *(const f32x4*)(cs + lr * CS_LD + col + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                if (g.bias) {
+                    const f32x4 b0 = *(const f32x4*)(g.bias + gn), b1 = *(const f32x4*)(g.bias + gn + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (g.act == UNITE_ACT_GELU) {
+                    if (g.aux_out) {
+                        u32x4 z = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                        *(u32x4*)((uint16_t*)g.aux_out + (size_t)gm * g.ld_aux_out + gn) = z;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                } else if (g.act == UNITE_ACT_QUICKGELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
+                } else if (g.act == UNITE_ACT_DGELU) {
+                    const u32x4 z = *(const u32x4*)((const uint16_t*)g.aux_in + (size_t)gm * g.ld_aux_in + gn);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] *= gelu_erf_grad(__uint_as_float(z[e] << 16));
+                        v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(z[e] & 0xFFFF0000u));
+                    }
+                }
+                if (g.row_scale) {
+                    const float s = g.row_scale[gm / g.rows_per_scale];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= s;
+                }
+                if (g.residual) {
+                    const float* rp = g.residual + (size_t)gm * g.ldr + gn;
+                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                }
+                if (g.out_f32) {
+                    float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
+                    if (g.accumulate) {
+                        const f32x4 o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+                    }
+                    *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+                }
+                if (g.out_bf16_copy) {
+                    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
+    if (!args) return UNITE_EINVAL;
+    const unite_gemm_args& g = *args;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.out) return UNITE_EINVAL;
+    if ((g.lda & 7) || (g.ldb & 7) || (g.N & 7) || (g.ldc & 7)) return UNITE_EINVAL;
+    if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.out)) return UNITE_EINVAL;
+    if ((g.trans_a ? (g.M & 7) : (g.K & 7)) || (g.trans_b ? 0 : (g.K & 7))) return UNITE_EINVAL;
+    if (g.accumulate && !g.out_f32) return UNITE_EINVAL;
+    if (g.act == UNITE_ACT_DGELU && (!g.aux_in || (g.ld_aux_in & 7))) return UNITE_EINVAL;
+    if (g.aux_out && (g.ld_aux_out & 7)) return UNITE_EINVAL;
+    if (g.row_scale && g.rows_per_scale <= 0) return UNITE_EINVAL;
+    if (g.residual && (g.ldr & 3)) return UNITE_EINVAL;
+    if (g.out_bf16_copy && (g.ld_copy & 7)) return UNITE_EINVAL;
+    const int64_t a_rows = g.trans_a ? g.K : g.M, a_cols = g.trans_a ? g.M : g.K;
+    const int64_t b_rows = g.trans_b ? g.K : g.N, b_cols = g.trans_b ? g.N : g.K;
+    const int64_t a_bytes = ((a_rows - 1) * g.lda + a_cols) * 2, b_bytes = ((b_rows - 1) * g.ldb + b_cols) * 2;
+    if (a_bytes >= (int64_t)OOB_OFFSET || b_bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
+    Params p;
+    p.a = g;
+    p.a_bytes = (uint32_t)a_bytes;
+    p.b_bytes = (uint32_t)b_bytes;
+    const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipStream_t s = (hipStream_t)stream;
+    if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

@@ -1,0 +1,323 @@
+// Gather / index / small reduction kernels of the stage-1 step (all HBM- or latency-bound, no MFMA).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ im2col of the listed tokens
+// One wavefront per patch row of 3*P*P elements; each lane moves float4 pieces (4 pixels of one 64-B patch line).
+__global__ __launch_bounds__(256) void im2col_gather_kernel(const float* __restrict__ video, const int32_t* __restrict__ token_index,
+                                                            uint16_t* __restrict__ cols, int n_rows, int B, int T, int H, int W, int P) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int GH = H / P, GW = W / P;
+    const int tok = token_index ? token_index[row] : row;
+    const int gw = tok % GW, gh = (tok / GW) % GH, t = (tok / (GW * GH)) % T, b = tok / (GW * GH * T);
+    const int PP = P * P, KD = 3 * PP;
+    const size_t plane = (size_t)H * W;
+    for (int e = lane * 4; e < KD; e += 256) {
+        const int c = e / PP, ph = (e % PP) / P, pw = e % P;
+        const float* src = video + (((size_t)b * 3 + c) * T + t) * plane + (size_t)(gh * P + ph) * W + gw * P + pw;
+        const f32x4 v = *(const f32x4*)src;
+        *(u32x2*)(cols + (size_t)row * KD + e) = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ index, int modulo,
+                                                          float* __restrict__ out, int n_rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    int src = index ? index[row] : row;
+    if (modulo > 0) src %= modulo;
+    for (int c = lane * 4; c < D; c += 256) *(f32x4*)(out + (size_t)row * D + c) = *(const f32x4*)(table + (size_t)src * D + c);
+}
+
+// ------------------------------------------------------------------------------------ column sums (bias gradients)
+constexpr int CS_ROWS = 256;   // rows per workgroup
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __restrict__ x, int ldx, int M, int N,
+                                                             float* __restrict__ partial) {
+    // block (bx, by): columns [bx*512, +512) as 64 lanes x 8, rows [by*256, +256) split over 4 waves
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < N) {
+        const int r_end = min(M, (int)(blockIdx.y + 1) * CS_ROWS);
+        for (int r = blockIdx.y * CS_ROWS + wave; r < r_end; r += 4) {
+            const u32x4 w = *(const u32x4*)(x + (size_t)r * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += __uint_as_float(w[e] << 16);
+                acc[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc < N) partial[(size_t)blockIdx.y * N + gc] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
+                                                           int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float a = 0.f;
+    for (int i = 0; i < nparts; ++i) a += partial[(size_t)i * N + c];
+    out[c] = accumulate ? out[c] + a : a;
+}
+
+// ------------------------------------------------------------------------------------ mask sampling
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// one workgroup (256 threads) per frame row; N <= 256.  keys in LDS; rank by counting; ascending compaction by scan.
+__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const int64_t* __restrict__ importance,
+                                                          uint8_t* __restrict__ mask, int32_t* __restrict__ vis_tokens, int BT, int N, int n_vis) {
+    __shared__ float key[256];
+    __shared__ int flag[256];
+    const int bt = blockIdx.x, j = threadIdx.x;
+    int visible = 0;
+    if (importance) {
+        flag[j] = 0;
+        __syncthreads();
+        if (j < n_vis) flag[(int)importance[(size_t)bt * N + j]] = 1;
+        __syncthreads();
+        visible = (j < N) ? flag[j] : 0;
+    } else {
+        float k = INFINITY;
+        if (j < N) {
+            const float w = weights[(size_t)bt * N + j];
+            const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)bt << 20) + (uint64_t)j + 1));
+            const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
+            k = (w > 0.f) ? -__logf(u) / w : INFINITY;                             // exponential race
+        }
+        key[j] = k;
+        __syncthreads();
+        if (j < N) {
+            int rank = 0;
+            for (int i = 0; i < N; ++i) {
+                const float ki = key[i];
+                rank += (ki < k) || (ki == k && i < j);
+            }
+            visible = rank < n_vis;
+        }
+    }
+    if (j < N) mask[(size_t)bt * N + j] = visible ? 0 : 1;
+    // ascending compaction of the visible positions
+    __syncthreads();
+    flag[j] = visible;
+    __syncthreads();
+    if (visible) {
+        int pos = 0;
+        for (int i = 0; i < j; ++i) pos += flag[i];
+        vis_tokens[(size_t)bt * n_vis + pos] = bt * N + j;
+    }
+}
+
+// ------------------------------------------------------------------------------------ CLS-row attention probabilities
+// one workgroup per frame (bt); thread j <-> key j; loops over heads.  qkv packed [B*N, 3*H*64].
+__global__ __launch_bounds__(256) void attn_cls_probs_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ probs, int N, int H,
+                                                             float scale) {
+    __shared__ float q[64];
+    __shared__ float red[4];
+    const int bt = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const int ld = 3 * H * 64;
+    float accp = 0.f;
+    for (int h = 0; h < H; ++h) {
+        __syncthreads();
+        if (j < 64) q[j] = bf16_to_f32(qkv[(size_t)bt * N * ld + h * 64 + j]) * scale;
+        __syncthreads();
+        float s = -INFINITY;
+        if (j < N) {
+            const uint16_t* kp = qkv + ((size_t)bt * N + j) * ld + H * 64 + h * 64;
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; c += 8) {
+                const u32x4 w = *(const u32x4*)(kp + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d += q[c + 2 * e] * __uint_as_float(w[e] << 16);
+                    d += q[c + 2 * e + 1] * __uint_as_float(w[e] & 0xFFFF0000u);
+                }
+            }
+            s = d;
+        }
+        float m = wave_max(s);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        const float e = (j < N) ? __expf(s - m) : 0.f;
+        float t = wave_sum(e);
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        t = red[0] + red[1] + red[2] + red[3];
+        accp += e / t;
+    }
+    if (j >= 1 && j < N) probs[(size_t)bt * (N - 1) + (j - 1)] = accp / (float)H;
+}
+
+// ------------------------------------------------------------------------------------ token mean
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int D) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += x[((size_t)b * N + n) * D + c];
+    out[(size_t)b * D + c] = a / (float)N;
+}
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int accumulate, int N, int D,
+                                                             size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t e = i * 4;
+    const int c = (int)(e % D);
+    const size_t b = e / ((size_t)N * D);
+    f32x4 g = *(const f32x4*)(dout + b * D + c);
+    const float inv = 1.0f / (float)N;
+    g = (f32x4){g[0] * inv, g[1] * inv, g[2] * inv, g[3] * inv};
+    if (accumulate) {
+        const f32x4 o = *(const f32x4*)(dx + e);
+        g = (f32x4){g[0] + o[0], g[1] + o[1], g[2] + o[2], g[3] + o[3]};
+    }
+    *(f32x4*)(dx + e) = g;
+}
+
+// ------------------------------------------------------------------------------------ softmax cross-entropy (one wave per row)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ row_weight, float grad_scale, float* __restrict__ loss_sum,
+                                                         float* __restrict__ dlogits, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t lab = labels[row];
+    const float w = row_weight ? row_weight[row] : 1.0f;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, logits[(size_t)row * C + c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(logits[(size_t)row * C + c] - m);
+    s = wave_sum(s);
+    const bool valid = lab >= 0 && lab < C;
+    if (dlogits) {
+        for (int c = lane; c < C; c += 64) {
+            const float p = __expf(logits[(size_t)row * C + c] - m) / s;
+            dlogits[(size_t)row * C + c] = valid ? grad_scale * w * (p - (c == lab ? 1.f : 0.f)) : 0.f;
+        }
+    }
+    if (loss_sum && valid && lane == 0) atomicAdd(loss_sum, w * (logf(s) + m - logits[(size_t)row * C + lab]));
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const f32x4 a = *(const f32x4*)(src + i), b = *(const f32x4*)(src + i + 4);
+            *(u32x4*)(dst + i) = (u32x4){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+        } else {
+            for (int64_t k = i; k < n; ++k) dst[k] = f32_to_bf16(src[k]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t n_rows, int32_t B, int32_t T,
+                                   int32_t H, int32_t W, int32_t P, void* stream) {
+    if (!video || !cols || n_rows <= 0 || P <= 0 || (P & 3) || H % P || W % P || (W & 3)) return UNITE_EINVAL;
+    hipLaunchKernelGGL(im2col_gather_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, video, token_index,
+                       (uint16_t*)cols, n_rows, B, T, H, W, P);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modulo, float* out, int32_t n_rows, int32_t D,
+                                     void* stream) {
+    if (!table || !out || n_rows <= 0 || D <= 0 || (D & 3)) return UNITE_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, index, modulo, out, n_rows, D);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" size_t unite_colsum_workspace(int32_t M, int32_t N) {
+    return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
+}
+
+extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* workspace,
+                                 void* stream) {
+    if (!x || !out || !workspace || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UNITE_EINVAL;
+    const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N,
+                       (float*)workspace);
+    UNITE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t BT, int32_t N,
+                                 int32_t n_vis, void* stream) {
+    if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const int64_t*)nullptr, mask,
+                       vis_tokens, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t BT, int32_t N,
+                                          int32_t n_vis, void* stream) {
+    if (!importance || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, importance, mask,
+                       vis_tokens, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
+    if (!qkv || !probs || B <= 0 || N <= 1 || N > 256 || H <= 0) return UNITE_EINVAL;
+    hipLaunchKernelGGL(attn_cls_probs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, probs, N, H, scale);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_token_mean_fwd(const float* x, float* out, int32_t B, int32_t N, int32_t D, void* stream) {
+    if (!x || !out || B <= 0 || N <= 0 || D <= 0) return UNITE_EINVAL;
+    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, out, N, D);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_token_mean_bwd(const float* dout, float* dx, int32_t accumulate, int32_t B, int32_t N, int32_t D, void* stream) {
+    if (!dout || !dx || B <= 0 || N <= 0 || D <= 0 || (D & 3)) return UNITE_EINVAL;
+    const size_t total4 = (size_t)B * N * D / 4;
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, accumulate,
+                       N, D, total4);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_softmax_ce(const float* logits, const int64_t* labels, const float* row_weight, float grad_scale, float* loss_sum,
+                                float* dlogits, int32_t M, int32_t C, void* stream) {
+    if (!logits || !labels || M <= 0 || C <= 0 || C > 1024) return UNITE_EINVAL;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels, row_weight, grad_scale,
+                       loss_sum, dlogits, M, C);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return UNITE_EINVAL;
+    const int64_t blocks = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks))), dim3(256), 0,
+                       (hipStream_t)stream, src, (uint16_t*)dst, n);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

@@ -1,0 +1,474 @@
+// Row-wise normalisation kernels for gfx950: one 64-lane wavefront per row, the row held in registers
+// (D <= 1024 -> <= 16 floats per lane, read as float4), fp32 statistics by wavefront shuffles.
+// All of them are HBM-bound streaming kernels: 16-byte loads, 8/16-byte stores, no LDS except for the
+// per-workgroup partial sums of the gamma/beta gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK_BWD = 32;    // 4 waves x 8 rows: dgamma/dbeta partial sums per workgroup
+
+template <int NV>
+__device__ __forceinline__ void load_row(const float* row, int D, int lane, f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < D) ? *(const f32x4*)(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[NV], int D, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+}
+
+__device__ __forceinline__ void store4(void* y, int y_f32, size_t off, f32x4 o) {
+    if (y_f32) *(f32x4*)((float*)y + off) = o;
+    else *(u32x2*)((uint16_t*)y + off) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ row_index,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ post_add, void* __restrict__ y, int y_f32,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int src = row_index ? row_index[row] : row;
+    f32x4 v[NV];
+    load_row<NV>(x + (size_t)src * ldx, D, lane, v);
+    float mean, rstd;
+    row_stats<NV>(v, D, lane, eps, mean, rstd);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (post_add) {
+                const f32x4 a = *(const f32x4*)(post_add + (size_t)row * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += a[e];
+            }
+            store4(y, y_f32, (size_t)row * D + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+// dx = rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat));  dgamma = sum_rows dy*xhat; dbeta = sum_rows dy
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dx_residual,
+                                                            float* __restrict__ dx_out, void* __restrict__ dx_bf16,
+                                                            const float* __restrict__ row_scale, int rows_per_scale,
+                                                            float* __restrict__ partial, int M, int D) {
+    __shared__ float red[4][2][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        gam[i] = (c < D) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
+        const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
+        if (row >= M) break;
+        f32x4 xv[NV], dyv[NV];
+        load_row<NV>(x + (size_t)row * ldx, D, lane, xv);
+        if (dy_f32) load_row<NV>((const float*)dy + (size_t)row * D, D, lane, dyv);
+        else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    const u32x2 w = *(const u32x2*)((const uint16_t*)dy + (size_t)row * D + c);
+                    dyv[i] = (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u),
+                                     __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u)};
+                } else dyv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[i][e] - mu) * rs;
+                const float gd = gam[i][e] * dyv[i][e];
+                s1 += gd;
+                s2 += gd * xh;
+                dg[i][e] += dyv[i][e] * xh;
+                db[i][e] += dyv[i][e];
+                xv[i][e] = xh;
+            }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        const float sc = row_scale ? row_scale[row / rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gam[i][e] * dyv[i][e] - s1 - xv[i][e] * s2);
+                if (dx_residual) {
+                    const f32x4 a = *(const f32x4*)(dx_residual + (size_t)row * D + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += a[e];
+                }
+                if (dx_out) *(f32x4*)(dx_out + (size_t)row * D + c) = o;
+                if (dx_bf16)
+                    *(u32x2*)((uint16_t*)dx_bf16 + (size_t)row * D + c) =
+                        (u32x2){pack_bf16x2(sc * o[0], sc * o[1]), pack_bf16x2(sc * o[2], sc * o[3])};
+            }
+        }
+    }
+    // workgroup partial sums -> partial[block][2][D]
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][(i * 64 + lane) * 4 + e] = dg[i][e];
+            red[wave][1][(i * 64 + lane) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+// out_a[c] (+)= sum_b partial[b][0][c], out_b[c] (+)= sum_b partial[b][1][c]; fixed order -> deterministic
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                              float* __restrict__ out_a, float* __restrict__ out_b, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nblocks; ++i) {
+        a += partial[((size_t)i * 2 + 0) * D + c];
+        b += partial[((size_t)i * 2 + 1) * D + c];
+    }
+    if (out_a) out_a[c] = accumulate ? out_a[c] + a : a;
+    if (out_b) out_b[c] = accumulate ? out_b[c] + b : b;
+}
+
+// ------------------------------------------------------------------------------------ decoder tail
+// u = LN(y)*g+b ; o = u/||u|| ; loss += 2 - 2<o,t>
+template <int NV>
+__global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, const float* __restrict__ tgt,
+                                                               float* __restrict__ out, float* __restrict__ loss_sum, int M, int C) {
+    __shared__ float wl[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float l = 0.f;
+    if (row < M) {
+        f32x4 v[NV];
+        load_row<NV>(y + (size_t)row * C, C, lane, v);
+        float mean, rstd;
+        row_stats<NV>(v, C, lane, eps, mean, rstd);
+        float nn = 0.f, dt = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+                f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (tgt) t = *(const f32x4*)(tgt + (size_t)row * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = (v[i][e] - mean) * rstd * g[e] + b[e];
+                    v[i][e] = u;
+                    nn += u * u;
+                    dt += u * t[e];
+                }
+            }
+        }
+        nn = wave_sum(nn);
+        dt = wave_sum(dt);
+        const float inv = rsqrtf(nn);
+        if (out) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < C) *(f32x4*)(out + (size_t)row * C + c) = (f32x4){v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
+            }
+        }
+        l = 2.0f - 2.0f * dt * inv;
+    }
+    if (loss_sum && tgt) {
+        if (lane == 0) wl[wave] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss_sum, wl[0] + wl[1] + wl[2] + wl[3]);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, const float* __restrict__ tgt,
+                                                               float loss_scale, const float* __restrict__ dout, void* __restrict__ dy_bf16,
+                                                               float* __restrict__ partial, int M, int C) {
+    __shared__ float red[4][2][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 gam[NV], bet[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        gam[i] = (c < C) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bet[i] = (c < C) ? *(const f32x4*)(beta + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
+        const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
+        if (row >= M) break;
+        f32x4 v[NV], u[NV], dov[NV];
+        load_row<NV>(y + (size_t)row * C, C, lane, v);
+        float mean, rstd;
+        row_stats<NV>(v, C, lane, eps, mean, rstd);
+        if (dout) load_row<NV>(dout + (size_t)row * C, C, lane, dov);
+        else {
+            load_row<NV>(tgt + (size_t)row * C, C, lane, dov);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dov[i][e] *= -2.0f * loss_scale;
+        }
+        float nn = 0.f, od = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[i][e] - mean) * rstd;
+                const float uu = (c < C) ? xh * gam[i][e] + bet[i][e] : 0.f;
+                v[i][e] = (c < C) ? xh : 0.f;
+                u[i][e] = uu;
+                nn += uu * uu;
+                od += uu * dov[i][e];
+            }
+        }
+        nn = wave_sum(nn);
+        od = wave_sum(od);
+        const float inv = rsqrtf(nn);
+        // o = u*inv ; du = inv * (do - o <o,do>) = inv*do - u * inv^3 * <u,do>
+        const float k2 = inv * inv * inv * od;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float du = inv * dov[i][e] - u[i][e] * k2;
+                dg[i][e] += du * v[i][e];
+                db[i][e] += du;
+                const float gd = gam[i][e] * du;
+                u[i][e] = gd;
+                s1 += gd;
+                s2 += gd * v[i][e];
+            }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (u[i][e] - s1 - v[i][e] * s2);
+                *(u32x2*)((uint16_t*)dy_bf16 + (size_t)row * C + c) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][(i * 64 + lane) * 4 + e] = dg[i][e];
+            red[wave][1][(i * 64 + lane) * 4 + e] = db[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------ CLIP embed + ln_pre
+template <int NV>
+__global__ __launch_bounds__(256) void clip_embed_ln_kernel(const uint16_t* __restrict__ patches, const float* __restrict__ cls,
+                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float* __restrict__ x,
+                                                            int BT, int HW, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int L = HW + 1;
+    if (row >= BT * L) return;
+    const int bt = row / L, j = row % L;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            if (j == 0) v[i] = *(const f32x4*)(cls + c);
+            else {
+                const u32x2 w = *(const u32x2*)(patches + ((size_t)bt * HW + (j - 1)) * D + c);
+                v[i] = (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u),
+                               __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u)};
+            }
+            const f32x4 pe = *(const f32x4*)(pos + (size_t)j * D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
+        }
+    }
+    float mean, rstd;
+    row_stats<NV>(v, D, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            *(f32x4*)(x + (size_t)row * D + c) = o;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ x, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 v[NV];
+    load_row<NV>(x + (size_t)row * D, D, lane, v);
+    float nn = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) nn += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    const float inv = rsqrtf(wave_sum(nn));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) *(f32x4*)(x + (size_t)row * D + c) = (f32x4){v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
+    }
+}
+
+inline int nv_for(int D) { return (D + 255) / 256; }
+inline bool dim_ok(int D) { return D > 0 && D <= 1024 && (D & 3) == 0; }
+
+}  // namespace
+
+#define DISPATCH_NV(D, CALL)                  \
+    switch (nv_for(D)) {                      \
+        case 1: { constexpr int NV = 1; CALL; } break; \
+        case 2: { constexpr int NV = 2; CALL; } break; \
+        case 3: { constexpr int NV = 3; CALL; } break; \
+        default: { constexpr int NV = 4; CALL; } break; \
+    }
+
+extern "C" int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                                   float eps, const float* post_add, void* y, int32_t y_f32, float* mean, float* rstd,
+                                   int32_t M, int32_t D, void* stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
+                                      beta, eps, post_add, y, y_f32, mean, rstd, M, D));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" size_t unite_layernorm_bwd_workspace(int32_t M, int32_t D) {
+    const size_t nb = (size_t)(M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    return nb * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* x, int32_t ldx, const float* mean, const float* rstd,
+                                   const float* gamma, const float* dx_residual, float* dx_out, void* dx_bf16,
+                                   const float* row_scale, int32_t rows_per_scale, float* dgamma, float* dbeta, int32_t accumulate,
+                                   void* workspace, int32_t M, int32_t D, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !workspace || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
+    if (row_scale && rows_per_scale <= 0) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma,
+                                      dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
+    UNITE_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
+                           dbeta, accumulate);
+        UNITE_LAUNCH_CHECK();
+    }
+    return UNITE_OK;
+}
+
+extern "C" int unite_decoder_tail_fwd(const float* y, const float* gamma, const float* beta, float eps, const float* tgt, float* out,
+                                      float* loss_sum, int32_t M, int32_t C, void* stream) {
+    if (!y || !gamma || !beta || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, y, gamma, beta, eps, tgt, out,
+                                      loss_sum, M, C));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps, const float* tgt,
+                                      float loss_scale, const float* dout, void* dy_bf16, float* dgamma, float* dbeta,
+                                      int32_t accumulate, void* workspace, int32_t M, int32_t C, void* stream) {
+    if (!y || !gamma || !beta || !dy_bf16 || !workspace || (!tgt && !dout) || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, y, gamma, beta, eps, tgt, loss_scale,
+                                      dout, dy_bf16, (float*)workspace, M, C));
+    UNITE_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
+                           dbeta, accumulate);
+        UNITE_LAUNCH_CHECK();
+    }
+    return UNITE_OK;
+}
+
+extern "C" int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,
+                                   const float* gamma, const float* beta, float eps, float* x, int32_t BT, int32_t HW, int32_t D,
+                                   void* stream) {
+    if (!patches || !class_embedding || !positional_embedding || !gamma || !beta || !x || BT <= 0 || HW <= 0 || !dim_ok(D))
+        return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = BT * (HW + 1);
+    DISPATCH_NV(D, hipLaunchKernelGGL((clip_embed_ln_kernel<NV>), dim3((rows + 3) / 4), dim3(256), 0, s, (const uint16_t*)patches,
+                                      class_embedding, positional_embedding, gamma, beta, eps, x, BT, HW, D));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_l2_normalize_rows(float* x, int32_t M, int32_t D, void* stream) {
+    if (!x || M <= 0 || !dim_ok(D)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(D, hipLaunchKernelGGL((l2_normalize_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, x, M, D));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

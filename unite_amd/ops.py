@@ -1,0 +1,247 @@
+"""Tensor-level wrappers over the C ABI (include/unite_hip.h).  PyTorch supplies device memory and the
+stream; every device op below is a hand-written gfx950 kernel in libunite_hip.so -- there is no eager /
+CPU fallback, a CPU tensor raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_DGELU = 0, 1, 2, 3
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.UniteHipError("unite_amd device ops need CUDA(HIP) tensors; there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dim must be contiguous")
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+         bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
+         aux_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 1,
+         residual: Optional[torch.Tensor] = None, accumulate: bool = False,
+         out_bf16_copy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views."""
+    lib = _lib.load()
+    _req(a, BF16, "a"); _req(b, BF16, "b")
+    M, N = out.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    am = a.shape[1] if trans_a else a.shape[0]
+    bk = b.shape[0] if trans_b else b.shape[1]
+    bn = b.shape[1] if trans_b else b.shape[0]
+    if am != M or bn != N or bk != K:
+        raise ValueError(f"gemm shape mismatch: a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)} ta={trans_a} tb={trans_b}")
+    g = _lib.GemmArgs()
+    g.M, g.N, g.K = M, N, K
+    g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    g.A, g.lda = _ptr(a), a.stride(0)
+    g.B, g.ldb = _ptr(b), b.stride(0)
+    if bias is not None:
+        _req(bias, F32, "bias")
+    g.bias = _ptr(bias)
+    g.act = act
+    g.aux_in, g.ld_aux_in = _ptr(aux_in), (aux_in.stride(0) if aux_in is not None else 0)
+    g.aux_out, g.ld_aux_out = _ptr(aux_out), (aux_out.stride(0) if aux_out is not None else 0)
+    g.row_scale, g.rows_per_scale = _ptr(row_scale), rows_per_scale
+    if residual is not None:
+        _req(residual, F32, "residual")
+    g.residual, g.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
+    if out.dtype not in (BF16, F32):
+        raise TypeError("out must be bf16 or f32")
+    g.out, g.ldc, g.out_f32, g.accumulate = _ptr(out), out.stride(0), int(out.dtype == F32), int(accumulate)
+    g.out_bf16_copy, g.ld_copy = _ptr(out_bf16_copy), (out_bf16_copy.stride(0) if out_bf16_copy is not None else 0)
+    _lib.check(lib.unite_gemm_bf16(C.byref(g), _stream()), "unite_gemm_bf16")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, y: torch.Tensor, *, row_index=None, post_add=None,
+                  mean=None, rstd=None) -> torch.Tensor:
+    lib = _lib.load()
+    _req(x, F32, "x")
+    M, D = y.shape
+    _lib.check(lib.unite_layernorm_fwd(_ptr(x), x.stride(0), _ptr(row_index), _ptr(gamma), _ptr(beta), eps, _ptr(post_add),
+                                       _ptr(y), int(y.dtype == F32), _ptr(mean), _ptr(rstd), M, D, _stream()),
+               "unite_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd_workspace(M: int, D: int) -> int:
+    return int(_lib.load().unite_layernorm_bwd_workspace(M, D))
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_residual=None, dx_out=None, dx_bf16=None, row_scale=None,
+                  rows_per_scale: int = 1, dgamma=None, dbeta=None, accumulate: bool = False, workspace: torch.Tensor = None):
+    lib = _lib.load()
+    M, D = x.shape
+    _lib.check(lib.unite_layernorm_bwd(_ptr(dy), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                       _ptr(dx_residual), _ptr(dx_out), _ptr(dx_bf16), _ptr(row_scale), rows_per_scale,
+                                       _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace), M, D, _stream()),
+               "unite_layernorm_bwd")
+
+
+def colsum_workspace(M: int, N: int) -> int:
+    return int(_lib.load().unite_colsum_workspace(M, N))
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, accumulate: bool = False):
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    M, N = x.shape
+    _lib.check(lib.unite_colsum_bf16(_ptr(x), x.stride(0), M, N, _ptr(out), int(accumulate), _ptr(workspace), _stream()),
+               "unite_colsum_bf16")
+    return out
+
+
+def attn_fwd(qkv, out, lse, B: int, N: int, H: int, scale: float):
+    lib = _lib.load()
+    _req(qkv, BF16, "qkv")
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape[-1] == 3 * H * 64
+    _lib.check(lib.unite_attn_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, scale, _stream()), "unite_attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B: int, N: int, H: int, scale: float):
+    lib = _lib.load()
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    _lib.check(lib.unite_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dqkv), B, N, H, scale, _stream()),
+               "unite_attn_bwd")
+    return dqkv
+
+
+def attn_cls_probs(qkv, probs, B: int, N: int, H: int, scale: float):
+    lib = _lib.load()
+    _lib.check(lib.unite_attn_cls_probs(_ptr(qkv), _ptr(probs), B, N, H, scale, _stream()), "unite_attn_cls_probs")
+    return probs
+
+
+def im2col_gather(video, token_index, cols, P: int):
+    lib = _lib.load()
+    _req(video, F32, "video")
+    assert video.is_contiguous()
+    B, Cc, T, H, W = video.shape
+    assert Cc == 3
+    _lib.check(lib.unite_im2col_gather(_ptr(video), _ptr(token_index), _ptr(cols), cols.shape[0], B, T, H, W, P, _stream()),
+               "unite_im2col_gather")
+    return cols
+
+
+def gather_rows(table, index, out, modulo: int = 0):
+    lib = _lib.load()
+    _lib.check(lib.unite_gather_rows_f32(_ptr(table), _ptr(index), modulo, _ptr(out), out.shape[0], out.shape[1], _stream()),
+               "unite_gather_rows_f32")
+    return out
+
+
+def clip_embed_ln(patches, cls, pos, gamma, beta, eps: float, x, BT: int, HW: int, D: int):
+    lib = _lib.load()
+    _lib.check(lib.unite_clip_embed_ln(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), eps, _ptr(x), BT, HW, D, _stream()),
+               "unite_clip_embed_ln")
+    return x
+
+
+def l2_normalize_rows(x):
+    lib = _lib.load()
+    _lib.check(lib.unite_l2_normalize_rows(_ptr(x), x.shape[0], x.shape[1], _stream()), "unite_l2_normalize_rows")
+    return x
+
+
+def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int):
+    lib = _lib.load()
+    BT, N = weights.shape
+    _lib.check(lib.unite_mask_sample(_ptr(weights), seed & 0xFFFFFFFFFFFFFFFF, _ptr(mask), _ptr(vis_tokens), BT, N, n_vis, _stream()),
+               "unite_mask_sample")
+
+
+def mask_from_importance(importance, mask, vis_tokens, n_vis: int):
+    lib = _lib.load()
+    BT, N = importance.shape
+    assert importance.dtype == torch.int64 and importance.is_contiguous()
+    _lib.check(lib.unite_mask_from_importance(_ptr(importance), _ptr(mask), _ptr(vis_tokens), BT, N, n_vis, _stream()),
+               "unite_mask_from_importance")
+
+
+def decoder_tail_fwd(y, gamma, beta, eps: float, tgt, out, loss_sum):
+    lib = _lib.load()
+    M, Cd = y.shape
+    _lib.check(lib.unite_decoder_tail_fwd(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(tgt), _ptr(out), _ptr(loss_sum), M, Cd, _stream()),
+               "unite_decoder_tail_fwd")
+
+
+def decoder_tail_bwd(y, gamma, beta, eps: float, tgt, loss_scale: float, dout, dy_bf16, dgamma, dbeta, workspace,
+                     accumulate: bool = False):
+    lib = _lib.load()
+    M, Cd = y.shape
+    _lib.check(lib.unite_decoder_tail_bwd(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(tgt), loss_scale, _ptr(dout), _ptr(dy_bf16),
+                                          _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace), M, Cd, _stream()),
+               "unite_decoder_tail_bwd")
+
+
+def adamw_flat(param, grad, exp_avg, exp_avg_sq, param_bf16, chunk_group, lrs: Sequence[float], wds: Sequence[float],
+               beta1: float, beta2: float, eps: float, step: int, grad_scale=None, found_inf=None):
+    lib = _lib.load()
+    n = len(lrs)
+    lr_arr = (C.c_float * n)(*lrs)
+    wd_arr = (C.c_float * n)(*wds)
+    _lib.check(lib.unite_adamw_flat(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(param_bf16), _ptr(chunk_group),
+                                    param.numel(), lr_arr, wd_arr, n, beta1, beta2, eps, step, _ptr(grad_scale), _ptr(found_inf),
+                                    _stream()), "unite_adamw_flat")
+
+
+def cast_f32_bf16(src, dst):
+    lib = _lib.load()
+    _lib.check(lib.unite_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "unite_cast_f32_bf16")
+    return dst
+
+
+def grad_norm_workspace(n: int) -> int:
+    return int(_lib.load().unite_grad_norm_workspace(n))
+
+
+def grad_norm_flat(grad, norm_out, workspace, max_norm: float = 0.0, clip_coef_out=None):
+    lib = _lib.load()
+    _lib.check(lib.unite_grad_norm_flat(_ptr(grad), grad.numel(), max_norm, _ptr(norm_out), _ptr(clip_coef_out), _ptr(workspace), _stream()),
+               "unite_grad_norm_flat")
+    return norm_out
+
+
+def token_mean_fwd(x, out):
+    lib = _lib.load()
+    B, N, D = x.shape
+    _lib.check(lib.unite_token_mean_fwd(_ptr(x), _ptr(out), B, N, D, _stream()), "unite_token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(dout, dx, accumulate: bool = False):
+    lib = _lib.load()
+    B, N, D = dx.shape
+    _lib.check(lib.unite_token_mean_bwd(_ptr(dout), _ptr(dx), int(accumulate), B, N, D, _stream()), "unite_token_mean_bwd")
+    return dx
+
+
+def softmax_ce(logits, labels, loss_sum, dlogits=None, row_weight=None, grad_scale: float = 1.0):
+    lib = _lib.load()
+    M, Cc = logits.shape
+    _lib.check(lib.unite_softmax_ce(_ptr(logits), _ptr(labels), _ptr(row_weight), grad_scale, _ptr(loss_sum), _ptr(dlogits), M, Cc, _stream()),
+               "unite_softmax_ce")
