@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Stage-1 training throughput (clips/s) of the UNITE hot path on MI355X -- the metric of BASELINE.json.
+
+A "step" is one full stage-1 iteration on a batch of B=32 synthetic 8-frame 224x224 clips per GPU
+(BASELINE configs[1]): frozen CLIP-B/16 teacher forward -> attention-guided mask (mask_ratio 0.8) -> targets on the
+320 visible tokens -> ViT-B/16 student forward + decoders + UMT loss -> backward -> gradient all-reduce (N>1) ->
+global grad-norm -> AdamW.  Inputs are resident in HBM before the timed region; nothing is skipped inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel (gemm_bf16_kernel): algorithmic FLOPs / launch time, measured with HIP events
+                 on the launch stream in a second pass of the same steps (events off during the timed region so
+                 that `value` is undisturbed); step_mfma_frac_* put the whole step against the 2.5 PF/s bf16 peak.
+  cpu_baseline : the CPU oracle (oracle/umt_oracle.py, fp32 torch) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16 = 2.5e15            # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+GF_STUDENT, GF_TEACHER = 179.7e9, 282.5e9     # algorithmic FLOPs per clip, BASELINE.md section 2
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """oracle stage-1 step (teacher fwd, student fwd+bwd, grad-norm, AdamW) at BASELINE configs[0] (B=4), fp32, all host cores."""
+    from oracle import umt_oracle as O
+    from oracle.filler import fill_state_dict, make_importance, make_videos
+    from tests.shapes import student_shapes, teacher_shapes
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    scfg, tcfg = O.StudentCfg(), O.TeacherCfg()
+    ssd = fill_state_dict(student_shapes(scfg), 12)
+    tsd = fill_state_dict(teacher_shapes(tcfg), 11)
+    B = 4
+    vid = make_videos(B, 8, 224, 224, 13)
+    mask = O.mask_from_importance(make_importance(B * 8, 196, 14), 40, B)
+    m = {k: torch.zeros_like(v) for k, v in ssd.items()}
+    v = {k: torch.zeros_like(v) for k, v in ssd.items()}
+
+    def step(i):
+        leaf = {k: p.requires_grad_(True) for k, p in ssd.items()}
+        loss, *_ = O.stage1_loss(leaf, tsd, vid, mask, scfg, tcfg)
+        loss.backward()
+        O.grad_norm([p.grad for p in leaf.values()])
+        with torch.no_grad():
+            for k, p in leaf.items():
+                p.requires_grad_(False)
+                O.adamw_step(p, p.grad, m[k], v[k], i, 1.5e-4 * B / 256, 0.9, 0.95, 1e-8, 0.05 if p.ndim > 1 else 0.0)
+                p.grad = None
+
+    t0 = time.time()
+    step(1)                                   # warm-up
+    warm = time.time() - t0
+    n = max(1, min(6, int((seconds_budget - warm) / max(warm, 1e-3))))
+    t0 = time.time()
+    for i in range(n):
+        step(2 + i)
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed stage-1 steps at B={B} (8fx224^2, ViT-B/16 + CLIP-B/16, fp32 torch CPU oracle) after 1 warm-up; "
+                      f"{dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import unite_amd
+    from unite_amd import _lib
+    from unite_amd.ddp import DistributedDataParallel
+    from unite_amd.engine_stage1 import StepState, stage1_step
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
+    from types import SimpleNamespace
+
+    torch.manual_seed(0 + rank)                                   # run_stage1.py:613
+    B, T = a.batch, 8
+    student = unite_amd.create_model(
+        "adaptation_umt_base_patch16_224", pretrained=False, drop_path_rate=0.1, drop_block_rate=None, use_learnable_pos_emb=False,
+        use_checkpoint=False, checkpoint_num=0, clip_decoder_embed_dim=768, clip_output_dim=512, clip_norm_type='l2', num_frames=T,
+        tubelet_size=1, clip_return_layers=[6, 7, 8, 9, 10, 11], clip_student_return_interval=1, use_cls_token=False).to(dev).train()
+    teacher = unite_amd.clip.clip_b16(pretrained=False, return_attn=True, clip_return_layers=[6, 7, 8, 9, 10, 11]).to(dev)
+    model = DistributedDataParallel(student) if world > 1 else student
+    total_batch = B * world
+    args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1.5e-4 * total_batch / 256, opt_eps=1e-8, opt_betas=[0.9, 0.95])
+    opt = create_optimizer(args, student, skip_list=student.no_weight_decay())
+    scaler = NativeScalerWithGradNormCount()
+    n_iter = a.warmup + 2 * a.steps + 4
+    lr_sched = cosine_scheduler(args.lr, 1e-5, 1, n_iter, warmup_epochs=0)
+    reducer = getattr(model, "reducer", None)
+    videos = torch.randn(B, 3, T, 224, 224, device=dev)           # synthetic, ImageNet-normalised-like; resident in HBM
+    state = StepState()
+    state.seed = 1000 * rank
+    it = [0]
+
+    def step():
+        i = it[0]
+        for g in opt.param_groups:
+            g["lr"] = lr_sched[min(i, len(lr_sched) - 1)] * g["lr_scale"]
+        loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
+        opt.zero_grad()
+        gn = scaler(loss, opt, clip_grad=None, parameters=None, reducer=reducer)
+        it[0] += 1
+        return loss, gn
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss, gn = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, gn = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_v, gn_v = float(loss.item()), float(gn.item())
+    ms_step = dt / a.steps * 1e3
+    clips_s = total_batch * a.steps / dt
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        lib = _lib.load()
+        n_prof = min(a.steps, 5)
+        lib.unite_prof_enable(1, 400 * n_prof)
+        torch.cuda.synchronize()
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
+        lib.unite_prof_summary(C.byref(ms), C.byref(cnt), C.byref(fl))
+        lib.unite_prof_enable(0, 0)
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12,
+                "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None,
+                "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
+                "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
+                "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
+                "note": "HIP events on the launch stream around every GEMM launch in a second pass of the same step"}
+    elif world > 1:
+        # keep ranks in lock-step with rank 0's profiled pass
+        for _ in range(min(a.steps, 5)):
+            step()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        out = {"metric": "stage-1 train clips/sec (ViT-B/16, 8fx224^2)", "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "stage1 UMT pretrain, ViT-B/16 student + CLIP-B/16 teacher, synthetic 8fx224^2 clips, "
+                                      f"B={B}/GPU, mask_ratio=0.8, bf16 MFMA + fp32 accumulate/master (BASELINE configs[1])",
+                          "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05"},
+               "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5)}
+        if roof is not None:
+            out["roofline"] = roof
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,13 @@ typedef struct unite_gemm_args {
 
 int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
 
+/* Diagnostics for bench.py's roofline leg: when enabled, every unite_gemm_bf16 launch is bracketed by two HIP events
+ * recorded on the launch stream (pool of max_launches pairs; launches beyond the pool are not timed).
+ * unite_prof_summary synchronises on the recorded events and returns the summed durations (ms), the number of timed
+ * launches and their algorithmic FLOPs (2 M N K each).  Not for use under stream capture. */
+int unite_prof_enable(int32_t on, int32_t max_launches);
+int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops);
+
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (D % 4 == 0, D <= 1024), one wavefront per row, fp32 statistics.
  *   y[i,:] = LN(x[src(i),:]) * gamma + beta (+ post_add[i,:]),  src(i) = row_index ? row_index[i] : i
@@ -151,25 +158,32 @@ int unite_l2_normalize_rows(float* x, int32_t M, int32_t D, void* stream);
  * smallest): the same distribution as torch.multinomial(w, N)[:, :n_vis] as a SET.
  *   mask    : uint8 [BT*N], 1 = masked          vis_tokens : int32 [BT*n_vis] global token ids
  *   (bt*N + j), ascending -- the row order of x[~mask] (modeling_adaptation.py:153).
+ *   vis_rows_cls (optional) : int32 [BT*n_vis] = bt*(N+1) + 1 + j, the same tokens as rows of the
+ *   teacher's [BT, 1+N, D] activations (class token first, clip.py:150).
  * ------------------------------------------------------------------------------------ */
-int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens,
+int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                       int32_t BT, int32_t N, int32_t n_vis, void* stream);
 /* Same outputs from an explicit permutation (int64 [BT,N], the reference's `importance`). */
-int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens,
+int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                int32_t BT, int32_t N, int32_t n_vis, void* stream);
+/* Same outputs from a caller-supplied mask (uint8 [BT*N], 1 = masked, exactly n_vis zeros per row of N):
+ * the index form of x[~mask] (modeling_adaptation.py:153) for masks that did not come from the sampler. */
+int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                         int32_t BT, int32_t N, int32_t n_vis, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Decoder tail + UMT loss (modeling_adaptation.py:204-207, run_stage1.py:431):
  *   u = LN_eps(y) * gamma + beta ;  o = u / ||u||_2 ;  loss_sum += sum_rows (2 - 2 <o, tgt>)
  * y f32 [M,C] (C % 4 == 0, C <= 1024); out (f32 [M,C], optional) receives o; loss_sum is ONE f32
  * accumulator the caller zeroes (the caller divides by the row count of all taps).
- * Backward: d loss / d y for loss = loss_scale * sum_rows(2 - 2<o,tgt>)  (dout == NULL) or for an
+ * Backward: d loss / d y for loss = loss_scale * (loss_scale_dev ? *loss_scale_dev : 1) *
+ * sum_rows(2 - 2<o,tgt>)  (dout == NULL; loss_scale_dev is a device scalar, e.g. autograd's upstream gradient) or for an
  * explicit upstream gradient dout (f32 [M,C]);  dy bf16 [M,C]; dgamma/dbeta as in layernorm_bwd.
  * ------------------------------------------------------------------------------------ */
 int unite_decoder_tail_fwd(const float* y, const float* gamma, const float* beta, float eps,
                            const float* tgt, float* out, float* loss_sum, int32_t M, int32_t C, void* stream);
 int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps,
-                           const float* tgt, float loss_scale, const float* dout,
+                           const float* tgt, float loss_scale, const float* loss_scale_dev, const float* dout,
                            void* dy_bf16, float* dgamma, float* dbeta, int32_t accumulate,
                            void* workspace, int32_t M, int32_t C, void* stream);
 

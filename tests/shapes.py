@@ -1,5 +1,11 @@
-"""state_dict shape tables used to build full-size weights in tests
-without importing the reference."""
+"""state_dict shape tables used to build weights in tests without importing the reference,
+and the tiny configurations the golden fixtures were generated with (oracle/make_golden.py)."""
+from oracle import umt_oracle as O
+
+TINY_T = O.TeacherCfg(input_resolution=32, patch_size=16, width=128, layers=3, heads=2, output_dim=64, clip_return_layers=(1, 2))
+TINY_S = O.StudentCfg(img_size=32, patch_size=16, embed_dim=128, depth=3, num_heads=2, num_frames=2, tubelet_size=1,
+                      clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=(1, 2))
+TINY_V = O.VitCfg(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_classes=5, all_frames=4)
 
 
 def student_shapes(cfg):
@@ -37,4 +43,17 @@ def teacher_shapes(cfg):
               (b + "mlp.c_proj.weight", (W, 4 * W)), (b + "mlp.c_proj.bias", (W,)),
               (b + "ln_2.weight", (W,)), (b + "ln_2.bias", (W,))]
     s += [("ln_post.weight", (W,)), ("ln_post.bias", (W,))]
+    return s
+
+
+def vit_shapes(cfg):
+    D, H, p = cfg.embed_dim, 4 * cfg.embed_dim, cfg.patch_size
+    s = [("patch_embed.proj.weight", (D, 3, cfg.tubelet_size, p, p)), ("patch_embed.proj.bias", (D,))]
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        s += [(b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)), (b + "attn.q_bias", (D,)), (b + "attn.v_bias", (D,)),
+              (b + "attn.qkv.weight", (3 * D, D)), (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,)),
+              (b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)), (b + "mlp.fc1.weight", (H, D)), (b + "mlp.fc1.bias", (H,)),
+              (b + "mlp.fc2.weight", (D, H)), (b + "mlp.fc2.bias", (D,))]
+    s += [("fc_norm.weight", (D,)), ("fc_norm.bias", (D,)), ("head.weight", (cfg.num_classes, D)), ("head.bias", (cfg.num_classes,))]
     return s

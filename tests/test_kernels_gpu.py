@@ -259,9 +259,14 @@ def test_mask_from_importance_matches_reference_rule(ops):
     ref = O.mask_from_importance(imp, n_vis, B)
     mask = torch.empty(B * T * N, dtype=torch.uint8, device=DEV)
     vis = torch.empty(B * T * n_vis, dtype=torch.int32, device=DEV)
-    ops.mask_from_importance(imp.to(DEV), mask, vis, n_vis)
+    rows = torch.empty(B * T * n_vis, dtype=torch.int32, device=DEV)
+    ops.mask_from_importance(imp.to(DEV), mask, vis, n_vis, vis_rows_cls=rows)
     assert torch.equal(mask.cpu().bool().view(B, -1), ref)
     assert torch.equal(vis.cpu().long(), (~ref).view(-1).nonzero().flatten())     # row order of x[~mask]
+    assert torch.equal(rows.cpu(), vis.cpu() + vis.cpu() // N + 1)
+    vis2 = torch.empty_like(vis)
+    ops.mask_to_tokens(mask, vis2, n_vis, B * T, N)
+    assert torch.equal(vis2, vis)
 
 
 def test_mask_sample_properties_and_distribution(ops):

@@ -1,0 +1,235 @@
+"""End-to-end parity (-m gpu): the HIP path (unite_amd models on libunite_hip.so) against
+  (a) the CPU oracle on identical weights / clips / masks, and
+  (b) the golden vectors the REFERENCE itself produced (tests/golden, oracle/make_golden.py).
+Stated tolerances (bf16 GEMM operands, fp32 accumulation / statistics):
+  loss: relative 1e-3 (the north-star bound);  L2-normalised features: cosine >= 0.999;
+  teacher CLS attention: abs 2e-3 of values ~1/196;  gradients: relative L2 error per tensor <= 5e-2,
+  global grad-norm relative 2e-2.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import umt_oracle as O  # noqa: E402
+from oracle.filler import fill_state_dict, make_importance, make_videos  # noqa: E402
+from tests.shapes import TINY_S, TINY_T, student_shapes, teacher_shapes  # noqa: E402
+
+DEV = "cuda"
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def cos_min(a, b):
+    return torch.nn.functional.cosine_similarity(a.flatten(0, -2).float(), b.flatten(0, -2).float(), dim=-1).min().item()
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def build_tiny():
+    from unite_amd.modeling_adaptation import AdaptationVisionTransformer
+    from unite_amd.clip import VisionTransformer
+    from functools import partial
+    s = AdaptationVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=3, encoder_num_heads=2,
+                                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=2,
+                                    tubelet_size=1, clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=[1, 2])
+    t = VisionTransformer(input_resolution=32, patch_size=16, width=128, layers=3, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[1, 2])
+    return s, t
+
+
+def test_state_dict_contract_tiny():
+    s, t = build_tiny()
+    assert [(k, tuple(v.shape)) for k, v in s.state_dict().items()] == student_shapes(TINY_S)
+    assert sorted((k, tuple(v.shape)) for k, v in t.state_dict().items()) == sorted(teacher_shapes(TINY_T))
+
+
+def test_teacher_tiny_vs_reference_golden(golden_dir):
+    z = _load(golden_dir, "teacher_tiny.npz")
+    _, t = build_tiny()
+    t.load_state_dict(fill_state_dict(teacher_shapes(TINY_T), int(z["in.seed_weights"])))
+    t = t.to(DEV).eval()
+    feats, attn = t(torch.from_numpy(z["in.videos"]).to(DEV))
+    ref_f, ref_a = torch.from_numpy(z["out.feats"]), torch.from_numpy(z["out.attn"])
+    assert feats.shape == ref_f.shape and attn.shape == ref_a.shape
+    assert cos_min(feats.cpu(), ref_f) >= 0.999
+    torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=2e-2)
+
+
+def test_student_tiny_vs_reference_golden(golden_dir):
+    """forward (x_clip, x_vis), loss, every parameter gradient, and 3 AdamW steps -- all against the reference's vectors."""
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount
+    z = _load(golden_dir, "student_tiny.npz")
+    s, _ = build_tiny()
+    s.load_state_dict(fill_state_dict(student_shapes(TINY_S), int(z["in.seed_weights"])))
+    s = s.to(DEV).train()
+    vid = torch.from_numpy(z["in.videos"]).to(DEV)
+    mask = torch.from_numpy(z["in.mask"]).to(DEV)
+    tgt = torch.from_numpy(z["out.targets"]).to(DEV)
+    # generic autograd path: model(x, mask, clip_only=True) -> loss in torch -> backward
+    out = s(vid, mask, clip_only=True)
+    assert cos_min(out.detach().cpu(), torch.from_numpy(z["out.x_clip"])) >= 0.999
+    loss = (2 - 2 * (out * tgt).sum(dim=-1)).mean()
+    assert abs(loss.item() - float(z["out.loss"])) <= 1e-3 * abs(float(z["out.loss"]))
+    loss.backward()
+    worst = 0.0
+    for k, p in s.named_parameters():
+        e = rel_l2(p.grad.cpu(), torch.from_numpy(z["g." + k]))
+        worst = max(worst, e)
+        assert e <= 5e-2, (k, e)
+    # x_vis path
+    with torch.no_grad():
+        x_vis, x_clip = s(vid, mask, clip_only=False)
+    assert rel_l2(x_vis.cpu(), torch.from_numpy(z["out.x_vis"])) <= 2e-2
+    # fused loss path == generic path
+    K, B, n_vis, C = tgt.shape
+    rt = s.runtime()
+    vis, nv = rt.tokens_from_mask(mask)
+    assert nv == n_vis
+    g_generic = rt.fp.grad.clone()
+    s.zero_grad()
+    rt.fp.accumulate = False
+    loss2 = s.forward_loss(vid, vis, nv, tgt.reshape(K * B * n_vis, C))
+    loss2.backward()
+    assert abs(loss2.item() - loss.item()) <= 2e-4 * abs(loss.item())
+    assert rel_l2(rt.fp.grad, g_generic) <= 1e-2
+    # 3 optimizer steps through create_optimizer (param groups as the reference factory makes them)
+    args = SimpleNamespace(opt="adamw", weight_decay=float(z["opt.wd"]), lr=float(z["opt.lr"]), opt_eps=float(z["opt.eps"]),
+                           opt_betas=[float(b) for b in z["opt.betas"]])
+    opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+    names = {id(p): n for n, p in s.named_parameters()}
+    got = {("decay" if g["weight_decay"] > 0 else "no_decay"): [names[id(p)] for p in g["params"]] for g in opt.param_groups}
+    assert got["decay"] == list(z["groups.decay"]) and got["no_decay"] == list(z["groups.no_decay"])
+    scaler = NativeScalerWithGradNormCount()
+    for it in range(3):
+        opt.zero_grad()
+        l = s.forward_loss(vid, vis, nv, tgt.reshape(K * B * n_vis, C))
+        gn = scaler(l, opt, clip_grad=None, parameters=s.parameters())
+        assert abs(l.item() - z["out.losses3"][it]) <= 5e-3 * z["out.losses3"][it], (it, l.item(), z["out.losses3"][it])
+        assert abs(gn.item() - z["out.gnorms3"][it]) <= 5e-2 * z["out.gnorms3"][it], (it, gn.item(), z["out.gnorms3"][it])
+    sd = s.state_dict()
+    for k in [f[len("after3."):] for f in z if f.startswith("after3.")]:
+        a, r = sd[k].cpu(), torch.from_numpy(z["after3." + k])
+        # Adam normalises the step: an element whose gradient is ~0 moves by up to lr per step in EITHER direction whatever
+        # the rounding, so two correct trajectories can differ by 2*3*lr at isolated elements; the mean pins the rest.
+        assert (a - r).abs().max() <= 6.2 * float(z["opt.lr"]), k
+        assert (a - r).abs().mean() <= 0.1 * float(z["opt.lr"]), (k, (a - r).abs().mean())
+
+
+def test_drop_path_and_accumulation_tiny(golden_dir):
+    """stochastic depth with given keep-vectors vs the oracle; second backward without zero_grad accumulates."""
+    z = _load(golden_dir, "student_tiny.npz")
+    from functools import partial
+    from unite_amd.modeling_adaptation import AdaptationVisionTransformer
+    s = AdaptationVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=3, encoder_num_heads=2,
+                                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=2,
+                                    tubelet_size=1, clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=[1, 2],
+                                    drop_path_rate=0.5)
+    sd = fill_state_dict(student_shapes(TINY_S), 3)
+    s.load_state_dict(sd)
+    s = s.to(DEV).train()
+    vid = torch.from_numpy(z["in.videos"])
+    mask = torch.from_numpy(z["in.mask"])
+    tgt = torch.from_numpy(z["out.targets"])
+    rt = s.runtime()
+    u = torch.rand(3, 2, 2, generator=torch.Generator().manual_seed(5))
+    rates = torch.linspace(0, 0.5, 3)
+    keep = (1 - rates).view(-1, 1, 1)
+    scales = torch.floor(keep + u) / keep
+    rt.runner.drop_path_scales = lambda B, training: scales.to(DEV)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = O.student_forward(leaf, vid, mask, TINY_S, clip_only=True, drop_path_rate=0.5, training=True, dp_rand=u)
+    loss_ref = O.umt_loss(out_ref, tgt)
+    loss_ref.backward()
+    out = s(vid.to(DEV), mask.to(DEV), clip_only=True)
+    loss = (2 - 2 * (out * tgt.to(DEV)).sum(dim=-1)).mean()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-3 * abs(loss_ref.item())
+    loss.backward()
+    for k, p in s.named_parameters():
+        assert rel_l2(p.grad.cpu(), leaf[k].grad) <= 5e-2, k
+    g1 = rt.fp.grad.clone()
+    out = s(vid.to(DEV), mask.to(DEV), clip_only=True)
+    ((2 - 2 * (out * tgt.to(DEV)).sum(dim=-1)).mean()).backward()       # no zero_grad: gradients add up
+    assert rel_l2(rt.fp.grad, 2 * g1) <= 1e-3
+
+
+def test_stage1_vitb_vs_reference_golden(golden_dir):
+    """Full-size ViT-B/16 student + CLIP-B/16 teacher on 2 clips of 8x224x224: the engine's step (teacher -> mask from
+    the stored permutation -> visible targets -> fused loss -> backward) against numbers produced by the reference."""
+    import unite_amd
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    z = _load(golden_dir, "stage1_vitb_cfg1.npz")
+    B = int(z["in.B"])
+    student = unite_amd.create_model("adaptation_umt_base_patch16_224", pretrained=False, drop_path_rate=0.0, num_frames=8,
+                                     tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+                                     clip_return_layers=[6, 7, 8, 9, 10, 11], use_cls_token=False, use_learnable_pos_emb=False,
+                                     use_checkpoint=False, checkpoint_num=0, clip_norm_type='l2', clip_student_return_interval=1,
+                                     drop_block_rate=None)
+    teacher = unite_amd.clip.clip_b16(pretrained=False, return_attn=True, clip_return_layers=[6, 7, 8, 9, 10, 11])
+    assert sum(p.numel() for p in student.parameters()) == 88005888
+    student.load_state_dict(fill_state_dict(student_shapes(O.StudentCfg()), int(z["in.seed_student"])))
+    teacher.load_state_dict(fill_state_dict(teacher_shapes(O.TeacherCfg()), int(z["in.seed_teacher"])))
+    student, teacher = student.to(DEV).train(), teacher.to(DEV)
+    vid = make_videos(B, 8, 224, 224, int(z["in.seed_videos"])).to(DEV)
+    imp = make_importance(B * 8, 196, int(z["in.seed_importance"])).to(DEV)
+    st = StepState()
+    loss = stage1_step(student, teacher, vid, B, float(z["in.mask_ratio"]), 'attention', None, 'mixed', st, importance=imp)
+    # teacher side
+    attn = teacher.runtime().ws.bufs["attn"]
+    torch.testing.assert_close(attn.cpu(), torch.from_numpy(z["out.attn"]), atol=3e-4, rtol=5e-2)
+    tg = teacher.runtime().ws.bufs["targets"].view(6, B, 320, 512)
+    torch.testing.assert_close(tg[:, :, :8, :8].cpu(), torch.from_numpy(z["out.targets_corner"]), atol=6e-3, rtol=0)
+    assert st.mask.view(B, -1).sum(1).tolist() == [1248] * B
+    # loss within 1e-3 relative of the reference's fp32 CPU value
+    ref_loss = float(z["out.loss"])
+    assert abs(loss.item() - ref_loss) <= 1e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    loss.backward()
+    rt = student.runtime()
+    gn = rt.fp.grad.norm().item()
+    assert abs(gn - float(z["out.grad_norm"])) <= 2e-2 * float(z["out.grad_norm"]), (gn, float(z["out.grad_norm"]))
+    pg = dict(student.named_parameters())
+    for f in z:
+        if f.startswith("gnorm."):
+            k = f[len("gnorm."):]
+            g = pg[k].grad
+            assert abs(g.norm().item() - float(z[f])) <= 5e-2 * float(z[f]) + 1e-7, (k, g.norm().item(), float(z[f]))
+            corner = g.reshape(g.shape[0], -1)[:8, :8].cpu()
+            ref = torch.from_numpy(z["gcorner." + k])
+            assert (corner - ref).norm() <= 0.15 * ref.norm() + 1e-7, k
+
+
+def test_train_one_epoch_synthetic():
+    """The drop-in engine on a synthetic loader: attention-guided masks, 6 steps, loss goes down, meters come back."""
+    import unite_amd
+    from unite_amd.engine_stage1 import train_one_epoch
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
+    s, t = build_tiny()
+    torch.manual_seed(0)
+    s.load_state_dict(fill_state_dict(student_shapes(TINY_S), 3))
+    t.load_state_dict(fill_state_dict(teacher_shapes(TINY_T), 1))
+    s, t = s.to(DEV), t.to(DEV)
+    args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=2e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95], log_freq=2, epochs=1,
+                           clip_loss_data="mixed", seed=0)
+    opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+    vid = make_videos(4, 2, 32, 32, seed=9)
+    loader = [(vid, torch.full((4,), -1), torch.zeros(4, dtype=torch.long)) for _ in range(6)]
+    lr = cosine_scheduler(2e-3, 1e-5, 1, 6)
+    stats = train_one_epoch(s, loader, None, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), max_norm=None,
+                            start_steps=0, lr_schedule_values=lr, wd_schedule_values=None, teacher_model=t,
+                            clip_input_resolution=32, clip_loss_type='l2', mask_type='attention', mask_ratio=0.5, args=args)
+    assert set(stats) >= {"loss", "loss_clip", "grad_norm", "lr", "min_lr", "weight_decay", "loss_scale"}
+    assert np.isfinite(stats["loss"]) and 0.0 < stats["loss"] < 4.0
+    m = s._unite_stage1_state.mask.view(8, 4)
+    assert (m.sum(1) == 2).all()                    # N_vis = 4 - int(4*0.5) = 2 visible per frame
+    assert stats["loss"] < 2.3

@@ -44,6 +44,8 @@ SIGNATURES = {
     "unite_abi_version": (c_i, []),
     "unite_target_arch": (C.c_char_p, []),
     "unite_gemm_bf16": (c_i, [C.POINTER(GemmArgs), c_p]),
+    "unite_prof_enable": (c_i, [c_i, c_i]),
+    "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
@@ -56,10 +58,11 @@ SIGNATURES = {
     "unite_gather_rows_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_clip_embed_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "unite_l2_normalize_rows": (c_i, [c_p, c_i, c_i, c_p]),
-    "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_mask_to_tokens": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_decoder_tail_fwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
-    "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_adamw_flat": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
     "unite_cast_f32_bf16": (c_i, [c_p, c_p, c_i64, c_p]),
     "unite_grad_norm_workspace": (c_sz, [c_i64]),

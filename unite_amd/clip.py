@@ -1,0 +1,278 @@
+"""Frozen CLIP image teacher on the gfx950 kernels -- drop-in for reference src/models/clip.py.
+
+Same factories (``clip_b16`` / ``clip_l14`` / ``clip_l14_336``), keyword arguments, ``state_dict`` keys (OpenAI
+``visual.*`` layout with the 2-D conv1 inflated to 3-D) and ``forward(x) -> (feats (K,B,T*HW,C), attn (B*T,HW))``.
+The nn modules only hold parameters; the forward is a fixed launch schedule over libunite_hip.so:
+  conv1-as-GEMM -> [cls ; patches] + pos -> ln_pre -> 12 x (LN, qkv GEMM, fused attention, out_proj GEMM(+res),
+  LN, c_fc GEMM(+QuickGELU), c_proj GEMM(+res)) -> CLS-row attention probabilities of the last block ->
+  ln_post + proj + L2-norm on the VISIBLE tokens only (the reference computes the tail for all 1568, clip.py:168-173).
+The last block's head-averaged attention map (clip.py:95-96) is never materialised: only its CLS row is computed.
+
+Built for patch_size 16 / head_dim 64 (clip_b16).  clip_l14 (patch 14: 588-wide im2col rows are not 16-byte
+multiples) is declared but raises NotImplementedError until its padded patch-embed lands.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .flat_params import FlatParams
+from .vit_runner import Workspace, BF16, F32
+
+MODEL_PATH = os.environ.get("UNITE_CLIP_PATH", "your_model_path/clip_visual_encoder")
+_MODELS = {
+    "ViT-B/16": os.path.join(MODEL_PATH, "vit_b16.pth"),
+    "ViT-L/14": os.path.join(MODEL_PATH, "vit_l14.pth"),
+    "ViT-L/14_336": os.path.join(MODEL_PATH, "vit_l14_336.pth"),
+}
+
+
+class LayerNorm(nn.LayerNorm):
+    """parameter holder (reference clip.py:20-26 runs it in fp32; so do the kernels)."""
+
+
+class QuickGELU(nn.Module):
+    """marker module: x * sigmoid(1.702 x) is fused into the c_fc GEMM epilogue (reference clip.py:29-31)."""
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model, n_head, attn_mask=None):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)      # holds in_proj_weight/in_proj_bias/out_proj.*
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = LayerNorm(d_model)
+        self.attn_mask = attn_mask
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads, return_attn=False, clip_return_layers=[6, 7, 8, 9, 10, 11],
+                 clip_return_interval=1, return_cls=False):
+        super().__init__()
+        self.layers, self.return_attn, self.return_cls = layers, return_attn, return_cls
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
+        self.return_index = list(clip_return_layers)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, clip_norm_type='l2', kernel_size=1,
+                 return_attn=False, clip_return_layers=[6, 7, 8, 9, 10, 11], clip_return_interval=1, return_cls=False):
+        super().__init__()
+        if clip_norm_type != 'l2':
+            raise NotImplementedError("clip_norm_type must be 'l2'")
+        if kernel_size != 1 or return_cls:
+            raise NotImplementedError("kernel_size != 1 / return_cls are not built (unused by the UNITE configs)")
+        self.clip_norm_type, self.return_attn, self.return_cls = clip_norm_type, return_attn, return_cls
+        self.input_resolution, self.patch_size, self.width, self.heads = input_resolution, patch_size, width, heads
+        self.output_dim = output_dim
+        self.conv1 = nn.Conv3d(3, width, (kernel_size, patch_size, patch_size), (kernel_size, patch_size, patch_size), (0, 0, 0),
+                               bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads, return_attn=return_attn, clip_return_layers=clip_return_layers,
+                                       clip_return_interval=clip_return_interval, return_cls=return_cls)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self._rt: Optional[_TeacherRuntime] = None
+
+    def runtime(self) -> "_TeacherRuntime":
+        if self._rt is None:
+            dev = self.class_embedding.device
+            if dev.type != "cuda":
+                raise RuntimeError("unite_amd models run on a MI355X only: move the teacher to 'cuda' first (no CPU path)")
+            self._rt = _TeacherRuntime(self, dev)
+        return self._rt
+
+    def _apply(self, fn, *a, **k):
+        if self._rt is not None:
+            raise RuntimeError("teacher.to()/cuda() after the first forward would detach the flat parameter buffer")
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def forward(self, x, mask=None):
+        """reference clip.py:145-188 (mask=None path).  Returns feats (K,B,T*HW,C) [and attn (B*T,HW) if return_attn]."""
+        if mask is not None:
+            raise NotImplementedError("teacher-side token masking (clip.py:154-160) is unused by run_stage1/3 and not built")
+        rt = self.runtime()
+        attn = rt.forward_taps(x)
+        B, T = x.shape[0], x.shape[2]
+        feats = rt.targets(rt.all_rows(B * T), B * T * rt.HW).view(len(rt.taps), B, T * rt.HW, self.output_dim)
+        return (feats, attn) if self.return_attn else feats
+
+    @torch.no_grad()
+    def forward_attention(self, x):
+        """Engine entry: run the transformer once, keep the taps on device, return the CLS attention (B*T, HW)."""
+        return self.runtime().forward_taps(x)
+
+    @torch.no_grad()
+    def visible_targets(self, vis_rows_cls, n_rows):
+        """ln_post + proj + L2-norm of the taps at the listed rows only -> f32 [K*n_rows, C] (run_stage1.py:389-397)."""
+        return self.runtime().targets(vis_rows_cls, n_rows)
+
+
+class _TeacherRuntime:
+    def __init__(self, model: VisionTransformer, dev):
+        if model.patch_size % 4 or (3 * model.patch_size ** 2) % 8:
+            raise NotImplementedError("patch sizes whose im2col rows are not 16-byte multiples (CLIP-L/14) are not built yet")
+        if model.width != model.heads * 64:
+            raise NotImplementedError("head_dim must be 64")
+        self.model, self.dev = model, dev
+        self.fp = FlatParams(model, dev, with_grad=False)
+        for p in model.parameters():
+            p.requires_grad_(False)          # frozen (SURVEY A-18)
+        self.ws = Workspace(dev)
+        self.D, self.H, self.C, self.P = model.width, model.heads, model.output_dim, model.patch_size
+        self.HW = (model.input_resolution // model.patch_size) ** 2
+        self.L = self.HW + 1
+        self.layers = model.transformer.layers
+        self.taps: List[int] = list(model.transformer.return_index)
+        self.eps = model.ln_pre.eps
+        fp = self.fp
+        idx = {n: i for i, n in enumerate(fp.names)}
+
+        def P(n):
+            return fp.params[idx[n]].data
+
+        self.cls, self.pos = P("class_embedding"), P("positional_embedding")
+        self.ln_pre = (P("ln_pre.weight"), P("ln_pre.bias"))
+        self.ln_post = (P("ln_post.weight"), P("ln_post.bias"))
+        self.conv_w = fp.w16("conv1.weight")
+        self.proj_w = fp.w16("proj")
+        self.blk = []
+        for i in range(self.layers):
+            b = f"transformer.resblocks.{i}."
+            self.blk.append(dict(
+                ln1=(P(b + "ln_1.weight"), P(b + "ln_1.bias")), ln2=(P(b + "ln_2.weight"), P(b + "ln_2.bias")),
+                w_in=fp.w16(b + "attn.in_proj_weight"), b_in=P(b + "attn.in_proj_bias"),
+                w_out=fp.w16(b + "attn.out_proj.weight"), b_out=P(b + "attn.out_proj.bias"),
+                w_fc=fp.w16(b + "mlp.c_fc.weight"), b_fc=P(b + "mlp.c_fc.bias"),
+                w_pr=fp.w16(b + "mlp.c_proj.weight"), b_pr=P(b + "mlp.c_proj.bias")))
+        self._rows_cache = {}
+
+    def all_rows(self, BT: int) -> torch.Tensor:
+        t = self._rows_cache.get(BT)
+        if t is None:
+            j = torch.arange(BT * self.HW, dtype=torch.int32, device=self.dev)
+            t = (j + j // self.HW + 1).contiguous()
+            self._rows_cache[BT] = t
+        return t
+
+    def forward_taps(self, videos: torch.Tensor) -> torch.Tensor:
+        self.fp.refresh_if_stale()
+        ws, D, H, L, HW = self.ws, self.D, self.H, self.L, self.HW
+        B, Cc, T, Hh, Ww = videos.shape
+        if Hh != self.model.input_resolution or Ww != self.model.input_resolution:
+            raise ValueError("clip resolution mismatch")
+        BT = B * T
+        Mp, Mt = BT * HW, BT * L
+        Kpe = 3 * self.P * self.P
+        cols = ws.get("cols", (Mp, Kpe), BF16)
+        ops.im2col_gather(videos.contiguous(), None, cols, self.P)
+        patches = ws.get("patches", (Mp, D), BF16)
+        ops.gemm(cols, self.conv_w.view(D, Kpe), patches)
+        x = ws.get("x.a", (Mt, D), F32)
+        ops.clip_embed_ln(patches, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.eps, x, BT, HW, D)
+        h = ws.get("h", (Mt, D), BF16)
+        qkv = ws.get("qkv", (Mt, 3 * D), BF16)
+        o = ws.get("o", (Mt, D), BF16)
+        lse = ws.get("lse", (BT, H, L), F32)
+        x1 = ws.get("x1", (Mt, D), F32)
+        a = ws.get("a", (Mt, 4 * D), BF16)
+        scale = 64 ** -0.5
+        self._tap_bufs = []
+        for i in range(self.layers):
+            w = self.blk[i]
+            ops.layernorm_fwd(x, w["ln1"][0], w["ln1"][1], self.eps, h)
+            ops.gemm(h, w["w_in"], qkv, bias=w["b_in"])
+            ops.attn_fwd(qkv, o, lse, BT, L, H, scale)
+            ops.gemm(o, w["w_out"], x1, bias=w["b_out"], residual=x)
+            ops.layernorm_fwd(x1, w["ln2"][0], w["ln2"][1], self.eps, h)
+            ops.gemm(h, w["w_fc"], a, bias=w["b_fc"], act=ops.ACT_QUICKGELU)
+            if i in self.taps:
+                xo = ws.get(f"tap.{i}", (Mt, D), F32)      # kept until targets() gathers the visible rows
+                self._tap_bufs.append(xo)
+            else:
+                xo = ws.get("x.a", (Mt, D), F32)           # may alias x: the block input is dead after out_proj
+            ops.gemm(a, w["w_pr"], xo, bias=w["b_pr"], residual=x1)
+            x = xo
+        attn = ws.get("attn", (BT, HW), F32)
+        ops.attn_cls_probs(qkv, attn, BT, L, H, scale)          # qkv still holds the last block's projections
+        return attn
+
+    def targets(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
+        ws, D, C = self.ws, self.D, self.C
+        K = len(self.taps)
+        out = ws.get("targets", (K * n_rows, C), F32)
+        xn = ws.get("tail.xn", (n_rows, D), BF16)
+        for k in range(K):
+            ops.layernorm_fwd(self._tap_bufs[k], self.ln_post[0], self.ln_post[1], self.eps, xn, row_index=rows)
+            ops.gemm(xn, self.proj_w, out[k * n_rows:(k + 1) * n_rows], trans_b=True)
+        ops.l2_normalize_rows(out)
+        return out
+
+
+# ----------------------------------------------------------------------------- weights (reference clip.py:191-231)
+def inflate_weight(weight_2d, time_dim, center=True):
+    if center:
+        weight_3d = torch.zeros(*weight_2d.shape).unsqueeze(2).repeat(1, 1, time_dim, 1, 1)
+        weight_3d[:, :, time_dim // 2, :, :] = weight_2d
+    else:
+        weight_3d = weight_2d.unsqueeze(2).repeat(1, 1, time_dim, 1, 1) / time_dim
+    return weight_3d
+
+
+def load_state_dict(model, state_dict, input_resolution=224, patch_size=16, center=True):
+    """OpenAI visual.* checkpoint -> this model: inflate 2-D conv weights, bicubic-resize the position table."""
+    state_dict_3d = model.state_dict()
+    for k in state_dict.keys():
+        if k in state_dict_3d.keys() and state_dict[k].shape != state_dict_3d[k].shape:
+            if len(state_dict_3d[k].shape) <= 2:
+                continue
+            state_dict[k] = inflate_weight(state_dict[k], state_dict_3d[k].shape[2], center=center)
+    pos = state_dict['positional_embedding']
+    emb = pos.shape[-1]
+    num_patches = (input_resolution // patch_size) ** 2
+    orig_size, new_size = int((pos.shape[-2] - 1) ** 0.5), int(num_patches ** 0.5)
+    if orig_size != new_size:
+        extra, tok = pos[:1], pos[1:]
+        tok = tok.reshape(-1, orig_size, orig_size, emb).permute(0, 3, 1, 2)
+        tok = torch.nn.functional.interpolate(tok, size=(new_size, new_size), mode='bicubic', align_corners=False)
+        state_dict['positional_embedding'] = torch.cat((extra, tok.permute(0, 2, 3, 1).flatten(0, 2)), dim=0)
+    model.load_state_dict(state_dict, strict=True)
+
+
+def _build(name, pretrained, center, input_resolution, **kw):
+    model = VisionTransformer(input_resolution=input_resolution, **kw)
+    if pretrained:
+        sd = torch.load(_MODELS[name], map_location='cpu', weights_only=True)
+        load_state_dict(model, sd, input_resolution=input_resolution, patch_size=kw["patch_size"], center=center)
+    return model.eval()
+
+
+def clip_b16(pretrained=True, clip_norm_type='l2', input_resolution=224, kernel_size=1, return_attn=False, center=True,
+             clip_return_layers=[6, 7, 8, 9, 10, 11], clip_return_interval=1, return_cls=False):
+    return _build("ViT-B/16", pretrained, center, input_resolution, patch_size=16, width=768, layers=12, heads=12, output_dim=512,
+                  clip_norm_type=clip_norm_type, kernel_size=kernel_size, return_attn=return_attn,
+                  clip_return_layers=clip_return_layers, clip_return_interval=clip_return_interval, return_cls=return_cls)
+
+
+def clip_l14(pretrained=True, clip_norm_type='l2', input_resolution=224, kernel_size=1, return_attn=False, center=True,
+             clip_return_layers=[6, 7, 8, 9, 10, 11], clip_return_interval=1):
+    return _build("ViT-L/14", pretrained, center, input_resolution, patch_size=14, width=1024, layers=24, heads=16, output_dim=768,
+                  clip_norm_type=clip_norm_type, kernel_size=kernel_size, return_attn=return_attn,
+                  clip_return_layers=clip_return_layers, clip_return_interval=clip_return_interval)
+
+
+def clip_l14_336(pretrained=True, clip_norm_type='l2', input_resolution=336, kernel_size=1, return_attn=False, center=True,
+                 clip_return_layers=[6, 7, 8, 9, 10, 11], clip_return_interval=1):
+    return _build("ViT-L/14_336", pretrained, center, input_resolution, patch_size=14, width=1024, layers=24, heads=16, output_dim=768,
+                  clip_norm_type=clip_norm_type, kernel_size=kernel_size, return_attn=return_attn,
+                  clip_return_layers=clip_return_layers, clip_return_interval=clip_return_interval)

@@ -15,6 +15,8 @@
 // The accumulators leave through LDS so that the epilogue (bias, GELU / QuickGELU / GELU', stochastic-depth
 // row scale, residual add, bf16 + f32 outputs) reads and writes 16 B (bf16) / 32 B (f32) per lane.
 #include "common.h"
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -211,6 +213,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// launch-timing pool for bench.py's roofline leg (off by default; the only global state of this file)
+struct ProfState {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double flops = 0.0;
+};
+ProfState g_prof;
+
 }  // namespace
 
 extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
@@ -236,10 +247,46 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     p.b_bytes = (uint32_t)b_bytes;
     const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
+    const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
+    if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
     if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+        g_prof.used++;
+        g_prof.flops += 2.0 * g.M * g.N * g.K;
+    }
     UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+// ---- diagnostics (bench.py): HIP events around every GEMM launch, on the stream it is launched on
+extern "C" int unite_prof_enable(int32_t on, int32_t max_launches) {
+    if (on) {
+        while ((int)g_prof.ev.size() < max_launches) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return UNITE_EINVAL;
+            g_prof.ev.emplace_back(a, b);
+        }
+        g_prof.used = 0;
+        g_prof.flops = 0.0;
+    }
+    g_prof.on = on != 0;
+    return UNITE_OK;
+}
+
+extern "C" int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops) {
+    double ms = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.ev[i].second) != hipSuccess) return UNITE_EINVAL;
+        if (hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second) != hipSuccess) return UNITE_EINVAL;
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)g_prof.used;
+    if (total_flops) *total_flops = g_prof.flops;
     return UNITE_OK;
 }

@@ -80,12 +80,16 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 
 // one workgroup (256 threads) per frame row; N <= 256.  keys in LDS; rank by counting; ascending compaction by scan.
 __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const int64_t* __restrict__ importance,
-                                                          uint8_t* __restrict__ mask, int32_t* __restrict__ vis_tokens, int BT, int N, int n_vis) {
+                                                          const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask,
+                                                          int32_t* __restrict__ vis_tokens, int32_t* __restrict__ vis_rows_cls, int BT, int N,
+                                                          int n_vis) {
     __shared__ float key[256];
     __shared__ int flag[256];
     const int bt = blockIdx.x, j = threadIdx.x;
     int visible = 0;
-    if (importance) {
+    if (mask_in) {
+        visible = (j < N) ? (mask_in[(size_t)bt * N + j] == 0) : 0;
+    } else if (importance) {
         flag[j] = 0;
         __syncthreads();
         if (j < n_vis) flag[(int)importance[(size_t)bt * N + j]] = 1;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
             visible = rank < n_vis;
         }
     }
-    if (j < N) mask[(size_t)bt * N + j] = visible ? 0 : 1;
+    if (mask && j < N) mask[(size_t)bt * N + j] = visible ? 0 : 1;
     // ascending compaction of the visible positions
     __syncthreads();
     flag[j] = visible;
@@ -118,7 +122,10 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
     if (visible) {
         int pos = 0;
         for (int i = 0; i < j; ++i) pos += flag[i];
-        vis_tokens[(size_t)bt * n_vis + pos] = bt * N + j;
+        if (pos < n_vis) {
+            vis_tokens[(size_t)bt * n_vis + pos] = bt * N + j;
+            if (vis_rows_cls) vis_rows_cls[(size_t)bt * n_vis + pos] = bt * (N + 1) + 1 + j;
+        }
     }
 }
 
@@ -263,20 +270,29 @@ extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t 
     return UNITE_OK;
 }
 
-extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t BT, int32_t N,
-                                 int32_t n_vis, void* stream) {
+extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                                 int32_t BT, int32_t N, int32_t n_vis, void* stream) {
     if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const int64_t*)nullptr, mask,
-                       vis_tokens, BT, N, n_vis);
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const int64_t*)nullptr,
+                       (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
 
-extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t BT, int32_t N,
-                                          int32_t n_vis, void* stream) {
+extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                                          int32_t BT, int32_t N, int32_t n_vis, void* stream) {
     if (!importance || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, importance, mask,
-                       vis_tokens, BT, N, n_vis);
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, importance,
+                       (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls, int32_t BT, int32_t N,
+                                    int32_t n_vis, void* stream) {
+    if (!mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull,
+                       (const int64_t*)nullptr, mask, (uint8_t*)nullptr, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

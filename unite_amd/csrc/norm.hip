@@ -230,9 +230,11 @@ __global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const float* __re
 template <int NV>
 __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, const float* __restrict__ tgt,
-                                                               float loss_scale, const float* __restrict__ dout, void* __restrict__ dy_bf16,
+                                                               float loss_scale, const float* __restrict__ loss_scale_dev,
+                                                               const float* __restrict__ dout, void* __restrict__ dy_bf16,
                                                                float* __restrict__ partial, int M, int C) {
     __shared__ float red[4][2][NV * 256];
+    if (loss_scale_dev) loss_scale *= *loss_scale_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 gam[NV], bet[NV], dg[NV], db[NV];
 #pragma unroll
@@ -436,13 +438,13 @@ extern "C" int unite_decoder_tail_fwd(const float* y, const float* gamma, const 
 }
 
 extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps, const float* tgt,
-                                      float loss_scale, const float* dout, void* dy_bf16, float* dgamma, float* dbeta,
+                                      float loss_scale, const float* loss_scale_dev, const float* dout, void* dy_bf16, float* dgamma, float* dbeta,
                                       int32_t accumulate, void* workspace, int32_t M, int32_t C, void* stream) {
     if (!y || !gamma || !beta || !dy_bf16 || !workspace || (!tgt && !dout) || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
     DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, y, gamma, beta, eps, tgt, loss_scale,
-                                      dout, dy_bf16, (float*)workspace, M, C));
+                                      loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,

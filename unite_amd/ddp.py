@@ -1,0 +1,127 @@
+"""Data parallelism for the flat-gradient models: one process per GPU, gradient all-reduce (mean) over RCCL / xGMI.
+
+Replaces torch.nn.parallel.DistributedDataParallel as the reference uses it (run_stage1.py:809): parameters are
+broadcast from rank 0 once, and during backward each *bucket* -- a contiguous slice of the flat fp32 gradient
+buffer covering whole layers -- is all-reduced on a side HIP stream as soon as the last layer in it has written its
+gradients, so communication overlaps the remaining backward.  There are no packing copies (the buckets ARE the
+gradient storage) and no autograd hooks (the hand-scheduled backward reports layer completion itself).
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so buckets are large
+(default 64 MiB -> 6 collectives per step for ViT-B) rather than NCCL's 25 MiB default.
+
+``GradReducer`` is device-agnostic (it only needs a flat tensor, tag -> range table and a process group), which is
+how the N > 1 path is tested with gloo on CPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Hashable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradReducer:
+    def __init__(self, flat_grad: torch.Tensor, tag_ranges: Sequence[Tuple[Hashable, int, int]], bucket_bytes: int = 64 << 20,
+                 group=None):
+        """tag_ranges: (tag, start, end) element ranges in BACKWARD COMPLETION order; consecutive tags must be adjacent in
+        memory (descending addresses) for them to share a bucket."""
+        self.grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets: List[dict] = []
+        cur = None
+        for tag, lo, hi in tag_ranges:
+            if cur is not None and (lo == cur["hi"] or hi == cur["lo"]) and (cur["hi"] - cur["lo"]) * 4 < bucket_bytes:
+                cur["lo"], cur["hi"] = min(cur["lo"], lo), max(cur["hi"], hi)
+                cur["tags"].add(tag)
+            else:
+                cur = dict(lo=lo, hi=hi, tags={tag})
+                self.buckets.append(cur)
+        self.tag_bucket: Dict[Hashable, int] = {t: i for i, b in enumerate(self.buckets) for t in b["tags"]}
+        self.use_stream = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
+        self._pending: List[set] = []
+        self._works = []
+        self.reset()
+
+    def reset(self):
+        self._pending = [set(b["tags"]) for b in self.buckets]
+        self._works = []
+
+    def layer_done(self, tag):
+        """called by the backward when every gradient of `tag` has been written (on the current stream)."""
+        i = self.tag_bucket.get(tag)
+        if i is None:
+            return
+        self._pending[i].discard(tag)
+        if not self._pending[i]:
+            self._launch(i)
+
+    def _launch(self, i):
+        if self.world == 1:
+            return
+        b = self.buckets[i]
+        view = self.grad[b["lo"]:b["hi"]]
+        if self.use_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # gloo has no AVG
+            self._works.append((w, view))
+
+    def finish(self):
+        """join: every bucket reduced and visible to the current stream (call before grad-norm / optimizer)."""
+        for i, p in enumerate(self._pending):
+            if p:            # a layer never reported (e.g. unused parameters): reduce what is there
+                self._pending[i] = set()
+                self._launch(i)
+        if self.use_stream:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for w, view in self._works:
+                w.wait()
+                view.div_(self.world)
+        self.reset()
+
+
+def student_tag_ranges(rt) -> List[Tuple[Hashable, int, int]]:
+    """Backward completion order of the student's parameter layers with their flat ranges."""
+    fp = rt.fp
+    tags: List[Tuple[Hashable, str]] = [("clip_decoder", "clip_decoder.")]
+    depth = rt.depth
+    lo_tap = min(rt.taps)
+    for i in reversed(range(depth)):
+        tags.append((i, f"encoder.blocks.{i}."))
+    tags.append(("patch_embed", "encoder.patch_embed."))
+    ranges = fp.layer_ranges([p for _, p in tags])
+    out = [(t, lo, hi) for (t, _), (lo, hi) in zip(tags, ranges)]
+    # encoder.norm sits between blocks.{depth-1} and clip_decoder in memory but only completes with the lowest tap:
+    # it rides with the bucket of block `lo_tap + 1` by being reported then (see _StudentRuntime.backward_from_dy).
+    (nlo, nhi), = fp.layer_ranges(["encoder.norm."])
+    out.insert(1, ("norm", nlo, nhi))
+    return out
+
+
+class DistributedDataParallel(nn.Module):
+    """model wrapper with the reference's attribute surface (.module, forward passthrough)."""
+
+    def __init__(self, module: nn.Module, device_ids=None, find_unused_parameters: bool = False, bucket_cap_mb: int = 64,
+                 process_group=None):
+        super().__init__()
+        self.module = module
+        rt = module.runtime()
+        self.rt = rt
+        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            dist.broadcast(rt.fp.param, src=0, group=process_group)      # run_stage1.py:809 broadcasts rank 0's weights
+            rt.fp.sync_shadow()
+        self.reducer = GradReducer(rt.fp.grad, student_tag_ranges(rt), bucket_cap_mb << 20, process_group)
+        rt.layer_done_hook = self.reducer.layer_done
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def forward_loss(self, *a, **k):
+        return self.module.forward_loss(*a, **k)

@@ -1,0 +1,451 @@
+"""Stage-1/3 student: ``AdaptationVisionTransformer`` on the gfx950 kernels.
+
+Drop-in for reference src/models/modeling_adaptation.py: same class / factory names, constructor keywords,
+``forward(x, mask, clip_only)`` contract and ``state_dict`` keys, so checkpoints and
+``run_stage1.py``-style drivers interoperate.  The torch.nn modules below only HOLD parameters (and give them the
+reference's initialisation); all device arithmetic is in libunite_hip.so through ``ViTRunner`` -- calling forward
+on a CPU tensor raises, there is no eager fallback.
+
+Differences from the reference, all internal:
+  * only the visible tokens are patch-embedded (the reference embeds all 1568 and drops 80 %, :132,:153);
+  * the sinusoid tables are device constants (the reference re-uploads them every forward, :144,:318);
+  * bf16 GEMM operands / fp32 accumulation, residual stream and statistics in fp32, no GradScaler (SURVEY A-17).
+Not built (raise NotImplementedError): use_cls_token=True, use_learnable_pos_emb=True, tubelet_size != 1,
+head_dim != 64, use_checkpoint (no recomputation is needed with 288 GB of HBM: the flag is accepted and ignored).
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .flat_params import FlatParams
+from .registry import register_model
+from .vit_runner import ViTRunner, BF16, F32
+
+
+def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """pos / 10000^(2*(j//2)/d), sin on even j, cos on odd j (reference modeling_adaptation.py:41-51); (1, n, d) f32."""
+    j = np.arange(d_hid)
+    table = np.arange(n_position, dtype=np.float64)[:, None] / np.power(10000.0, 2.0 * (j // 2) / d_hid)[None, :]
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.tensor(table, dtype=torch.float32).unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------- parameter containers
+class _Attention(nn.Module):
+    def __init__(self, dim, qkv_bias):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            raise NotImplementedError("qkv_bias=False is not built (every UNITE factory sets qkv_bias=True)")
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Block(nn.Module):
+    """Parameter layout of reference Block (modeling_finetune.py:122-150), init_values = 0 branch."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=True, drop_path=0., norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _Attention(dim, qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.drop_path_rate = drop_path
+
+
+class PatchEmbed(nn.Module):
+    """Parameter layout of reference PatchEmbed (modeling_finetune.py:153-175): Conv3d weight (D,3,tubelet,P,P)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=16, tubelet_size=2):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.tubelet_size = int(tubelet_size)
+        self.num_patches = (img_size // patch_size) ** 2 * (num_frames // self.tubelet_size)
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=(self.tubelet_size, patch_size, patch_size),
+                              stride=(self.tubelet_size, patch_size, patch_size))
+
+
+def _init_weights(m):
+    # reference modeling_adaptation.py:108-115
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+class AdaptationVisionTransformerEncoder(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 norm_layer=nn.LayerNorm, init_values=None, num_frames=16, tubelet_size=2, use_checkpoint=False,
+                 checkpoint_num=0, use_learnable_pos_emb=False, clip_return_layers=[6, 7, 8, 9, 10, 11],
+                 clip_student_return_interval=1, use_cls_token=False):
+        super().__init__()
+        if use_cls_token or use_learnable_pos_emb:
+            raise NotImplementedError("use_cls_token / use_learnable_pos_emb are not built (UNITE configs: both False)")
+        if drop_rate or attn_drop_rate or (init_values or 0) > 0 or num_classes or qk_scale is not None:
+            raise NotImplementedError("dropout, layer-scale, encoder head and qk_scale are unused by UNITE and not built")
+        if in_chans != 3:
+            raise NotImplementedError("in_chans must be 3")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames, tubelet_size)
+        self.use_checkpoint, self.checkpoint_num = use_checkpoint, checkpoint_num
+        self.return_index = list(clip_return_layers)
+        self.use_learnable_pos_emb = False
+        self.pos_embed = get_sinusoid_encoding_table(self.patch_embed.num_patches, embed_dim)    # plain tensor, not in state_dict
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias, dpr[i], norm_layer) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Identity()
+        self.num_heads, self.mlp_ratio = num_heads, mlp_ratio
+        self.apply(_init_weights)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+
+class Linear_Decoder(nn.Module):
+    """Parameter layout of reference Linear_Decoder (modeling_adaptation.py:182-213)."""
+
+    def __init__(self, num_classes=768, embed_dim=768, norm_layer=nn.LayerNorm, clip_norm_type='l2'):
+        super().__init__()
+        if clip_norm_type != 'l2':
+            raise NotImplementedError("clip_norm_type must be 'l2' (all UNITE configs)")
+        self.clip_norm_type = clip_norm_type
+        self.head = nn.Linear(embed_dim, num_classes)
+        self.norm = norm_layer(num_classes)
+        self.apply(_init_weights)
+
+
+class AdaptationVisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, encoder_in_chans=3, encoder_num_classes=0, encoder_embed_dim=768,
+                 encoder_depth=12, encoder_num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_layer=nn.LayerNorm, init_values=0., use_learnable_pos_emb=False,
+                 use_cls_token=False, use_checkpoint=False, checkpoint_num=0, num_frames=16, tubelet_size=2,
+                 clip_decoder_embed_dim=768, clip_output_dim=512, clip_norm_type='l2',
+                 clip_return_layers=[6, 7, 8, 9, 10, 11], clip_student_return_interval=1):
+        super().__init__()
+        if tubelet_size != 1:
+            raise NotImplementedError("tubelet_size != 1 is not built (UNITE configs use 1)")
+        if clip_decoder_embed_dim != encoder_embed_dim:
+            raise ValueError("clip_decoder_embed_dim must equal the encoder width (the reference adds them, :320)")
+        self.encoder = AdaptationVisionTransformerEncoder(
+            img_size=img_size, patch_size=patch_size, in_chans=encoder_in_chans, num_classes=encoder_num_classes,
+            embed_dim=encoder_embed_dim, depth=encoder_depth, num_heads=encoder_num_heads, mlp_ratio=mlp_ratio,
+            qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+            drop_path_rate=drop_path_rate, norm_layer=norm_layer, init_values=init_values, num_frames=num_frames,
+            tubelet_size=tubelet_size, use_checkpoint=use_checkpoint, checkpoint_num=checkpoint_num,
+            use_learnable_pos_emb=use_learnable_pos_emb, clip_return_layers=clip_return_layers,
+            clip_student_return_interval=clip_student_return_interval, use_cls_token=use_cls_token)
+        self.clip_decoder = nn.ModuleList([
+            Linear_Decoder(num_classes=clip_output_dim, embed_dim=clip_decoder_embed_dim, norm_layer=norm_layer,
+                           clip_norm_type=clip_norm_type) for _ in range(len(clip_return_layers))])
+        self.clip_pos_embed = get_sinusoid_encoding_table(self.encoder.patch_embed.num_patches, clip_decoder_embed_dim)
+        self.ln_eps = self.encoder.norm.eps
+        self.clip_output_dim = clip_output_dim
+        self._rt: Optional["_StudentRuntime"] = None
+
+    def get_num_layers(self):
+        return len(self.encoder.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'mask_token', 'clip_mask_token', 'clip_pos_embed'}
+
+    # ------------------------------------------------------------------ runtime
+    def runtime(self) -> "_StudentRuntime":
+        """Flat parameter store + kernel schedule; created on first use, on the device the parameters live on."""
+        if self._rt is None:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("unite_amd models run on a MI355X only: move the model to 'cuda' first "
+                                   "(there is no CPU path; the CPU oracle lives in oracle/ for tests)")
+            self._rt = _StudentRuntime(self, dev)
+        return self._rt
+
+    def _apply(self, fn, *a, **k):
+        if self._rt is not None:
+            raise RuntimeError("model.to()/cuda()/float() after the first forward would detach the flat parameter buffer")
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x, mask, clip_only=False, vis_tokens=None, n_vis=None):
+        """x (B,3,T,H,W) f32; mask bool (B, T*196), True = masked.  Returns x_clip (K,B,n_vis,C) if clip_only else
+        (x_vis (B,n_vis,D), x_clip) -- reference :304-334.  ``vis_tokens`` (int32 [B*n_vis], ascending global token
+        ids) may be given instead of ``mask`` to skip the device sync that reading n_vis out of a mask needs."""
+        rt = self.runtime()
+        if vis_tokens is None:
+            vis_tokens, n_vis = rt.tokens_from_mask(mask)
+        return _StudentFn.apply(self, x, vis_tokens, n_vis, clip_only, rt.grad_anchor)
+
+    def forward_loss(self, x, vis_tokens, n_vis, targets):
+        """Fused stage-1 objective: mean(2 - 2 <decoder(x), targets>) over (K,B,n_vis) (run_stage1.py:431) without
+        materialising x_clip.  targets: f32 [K*B*n_vis, C] rows in (k, b, token) order, L2-normalised."""
+        rt = self.runtime()
+        return _StudentLossFn.apply(self, x, vis_tokens, n_vis, targets, rt.grad_anchor)
+
+
+class _StudentRuntime:
+    def __init__(self, model: AdaptationVisionTransformer, dev):
+        enc = model.encoder
+        self.model = model
+        self.fp = FlatParams(model, dev)
+        self.dev = dev
+        D = enc.embed_dim
+        self.D, self.C = D, model.clip_output_dim
+        self.taps: List[int] = list(enc.return_index)
+        self.depth = len(enc.blocks)
+        self.T_N = enc.patch_embed.num_patches
+        self.pos = enc.pos_embed[0].to(dev).contiguous()
+        self.clip_pos = model.clip_pos_embed[0].to(dev).contiguous()
+        self.runner = ViTRunner(self.fp, "encoder.", D, self.depth, enc.num_heads, int(D * enc.mlp_ratio), model.ln_eps,
+                                enc.patch_embed.patch_size[0], self.T_N, self.pos,
+                                [b.drop_path_rate for b in enc.blocks])
+        self.ws = self.runner.ws
+        # autograd anchor: gradients are written into the flat buffer by the backward itself; the anchor only makes
+        # autograd call it (loss.backward() works as in the reference engine, utils.py:609)
+        self.grad_anchor = torch.zeros((), device=dev, requires_grad=True)
+        fp = self.fp
+        idx = {n: i for i, n in enumerate(fp.names)}
+        self.norm_w, self.norm_b = fp.params[idx["encoder.norm.weight"]].data, fp.params[idx["encoder.norm.bias"]].data
+        self.g_norm_w, self.g_norm_b = fp.g("encoder.norm.weight"), fp.g("encoder.norm.bias")
+        self.dec = []
+        for k in range(len(self.taps)):
+            p = f"clip_decoder.{k}."
+            self.dec.append(dict(w=fp.w16(p + "head.weight"), b=fp.params[idx[p + "head.bias"]].data,
+                                 gw=fp.g(p + "head.weight"), gb=fp.g(p + "head.bias"),
+                                 nw=fp.params[idx[p + "norm.weight"]].data, nb=fp.params[idx[p + "norm.bias"]].data,
+                                 gnw=fp.g(p + "norm.weight"), gnb=fp.g(p + "norm.bias")))
+        self.layer_done_hook = None      # set by the data-parallel reducer
+        self.frame_tokens = (enc.patch_embed.img_size[0] // enc.patch_embed.patch_size[0]) ** 2
+
+    # -- mask -> token list (device sync: the number of visible tokens has to reach the host, as in x[~mask] of the reference)
+    def tokens_from_mask(self, mask: torch.Tensor):
+        B, L = mask.shape
+        m8 = mask.to(device=self.dev).to(torch.uint8).contiguous()
+        n_vis = int((m8[0] == 0).sum().item())
+        N = self.frame_tokens
+        T = L // N
+        if n_vis % T:
+            raise NotImplementedError("masks must keep the same number of tokens in every frame (attention masking does)")
+        vis = torch.empty(B * n_vis, dtype=torch.int32, device=self.dev)
+        ops.mask_to_tokens(m8.view(-1), vis, n_vis // T, B * T, N)
+        return vis, n_vis
+
+    # -- forward up to the decoder pre-activations
+    def forward_features(self, videos, vis_tokens, n_vis, clip_only, training):
+        fp, r, ws = self.fp, self.runner, self.ws
+        fp.refresh_if_stale()
+        B = videos.shape[0]
+        M = B * n_vis
+        D, C = self.D, self.C
+        n_blocks = (max(self.taps) + 1) if clip_only else self.depth       # early break, reference :165-166
+        dp = r.drop_path_scales(B, training)
+        x0 = r.embed(videos, vis_tokens, M)
+        xs = r.blocks_forward(x0, B, n_vis, n_blocks, dp, save=True)
+        cpos = ws.get("dec.pos", (M, D), F32)
+        ops.gather_rows(self.clip_pos, vis_tokens, cpos, modulo=self.T_N)
+        ys = []
+        self._tap = []
+        for k, li in enumerate(self.taps):
+            xt = xs[li + 1]
+            xn = ws.get(f"dec.xn{k}", (M, D), BF16)
+            mean, rstd = ws.get(f"dec.mean{k}", (M,), F32), ws.get(f"dec.rstd{k}", (M,), F32)
+            ops.layernorm_fwd(xt, self.norm_w, self.norm_b, self.model.ln_eps, xn, post_add=cpos, mean=mean, rstd=rstd)
+            y = ws.get(f"dec.y{k}", (M, C), F32)
+            d = self.dec[k]
+            ops.gemm(xn, d["w"], y, bias=d["b"])
+            ys.append(y)
+            self._tap.append(dict(x=xt, xn=xn, mean=mean, rstd=rstd, y=y))
+        self._ctx = dict(B=B, n_vis=n_vis, M=M, n_blocks=n_blocks, xs=xs, dp=dp, clip_only=clip_only)
+        return ys, xs
+
+    # -- backward from the decoder pre-activation gradients dy_k (bf16 [M,C], already computed into ws "dec.dy{k}")
+    def backward_from_dy(self, dxv: Optional[torch.Tensor] = None):
+        """dxv: optional f32 [M,D] gradient w.r.t. the returned x_vis = encoder.norm(x_out(last)) (clip_only=False)."""
+        fp, r, ws, ctx = self.fp, self.runner, self.ws, self._ctx
+        M, D, C, N = ctx["M"], self.D, self.C, ctx["n_vis"]
+        acc = fp.accumulate
+        dp = ctx["dp"]
+        lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, C)))
+        csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(r.Hd, 3 * D)))
+        # decoder heads: dgrad -> gradient of the normalised tap (bf16), wgrad/bias into the flat buffer
+        for k in range(len(self.taps)):
+            d, t = self.dec[k], self._tap[k]
+            dy = ws.bufs[f"dec.dy{k}"]
+            dxn = ws.get(f"dec.dxn{k}", (M, D), BF16)
+            ops.gemm(dy, d["w"], dxn, trans_b=True)
+            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.colsum(dy, d["gb"], csws, accumulate=acc)
+        if self.layer_done_hook is not None:
+            self.layer_done_hook("clip_decoder")
+        norm_first = [True]
+
+        def tap_grad(li, dx_in, scale):
+            """adds d/dx_out(li) of the shared encoder.norm branch of tap li; returns (dx f32, dx bf16 * scale)."""
+            k = self.taps.index(li)
+            t = self._tap[k]
+            out = ws.get(f"bw.dxt{li & 1}", (M, D), F32)
+            outb = ws.get("bw.dxtb", (M, D), BF16)
+            ops.layernorm_bwd(ws.bufs[f"dec.dxn{k}"], t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
+                              dx_bf16=outb, row_scale=scale, rows_per_scale=N, dgamma=self.g_norm_w, dbeta=self.g_norm_b,
+                              accumulate=(acc or not norm_first[0]), workspace=lnws)
+            norm_first[0] = False
+            if li == min(self.taps) and self.layer_done_hook is not None:
+                self.layer_done_hook("norm")      # encoder.norm's gradient is complete after the lowest tap
+            return out, outb
+
+        last = ctx["n_blocks"] - 1
+        dx_top = None
+        if dxv is not None:      # x_vis = encoder.norm(x_out(depth-1)) was returned and has an upstream gradient
+            dx_top = ws.get("bw.dxv", (M, D), F32)
+            xl = ctx["xs"][last + 1]
+            mean, rstd = ws.get("vis.mean", (M,), F32), ws.get("vis.rstd", (M,), F32)
+            ops.layernorm_bwd(dxv, xl, mean, rstd, self.norm_w, dx_out=dx_top, dgamma=self.g_norm_w, dbeta=self.g_norm_b,
+                              accumulate=acc, workspace=lnws)
+            norm_first[0] = False
+        s_last = None if dp is None else dp[last, 1]
+        if last in self.taps:
+            dx, dxb = tap_grad(last, dx_top, s_last)
+        else:
+            raise NotImplementedError("the last executed block must be a tap or carry an x_vis gradient")
+
+        def hook(li, dx_in, dxb_in, scale):
+            if li in self.taps:
+                return tap_grad(li, dx_in, scale)
+            return dx_in, dxb_in
+
+        def done(i):
+            if self.layer_done_hook is not None:
+                self.layer_done_hook(i)
+
+        dx0, dx0b = r.blocks_backward(dx, dxb, ctx["n_blocks"], tap_hook=hook, layer_done=done)
+        r.embed_backward(dx0b)
+        if self.layer_done_hook is not None:
+            self.layer_done_hook("patch_embed")
+        fp.accumulate = True        # a second backward before zero_grad() adds, as autograd would
+        fp.ensure_grad_views()      # p.grad may have been set to None by nn.Module.zero_grad()
+
+
+class _StudentFn(torch.autograd.Function):
+    """model(x, mask[, clip_only]) with autograd: returns the decoder outputs; backward takes d(x_clip)."""
+
+    @staticmethod
+    def forward(ctx, model, videos, vis_tokens, n_vis, clip_only, anchor):
+        rt = model.runtime()
+        ys, xs = rt.forward_features(videos, vis_tokens, n_vis, clip_only, model.training)
+        B, M, C, K = videos.shape[0], videos.shape[0] * n_vis, rt.C, len(rt.taps)
+        out = torch.empty(K, B, n_vis, C, dtype=F32, device=rt.dev)
+        for k in range(K):
+            d = rt.dec[k]
+            ops.decoder_tail_fwd(ys[k], d["nw"], d["nb"], model.ln_eps, None, out[k].view(M, C), None)
+        ctx.model, ctx.clip_only = model, clip_only
+        if clip_only:
+            return out
+        xv = torch.empty(B, n_vis, rt.D, dtype=F32, device=rt.dev)
+        mean, rstd = rt.ws.get("vis.mean", (M,), F32), rt.ws.get("vis.rstd", (M,), F32)
+        ops.layernorm_fwd(xs[-1], rt.norm_w, rt.norm_b, model.ln_eps, xv.view(M, rt.D), mean=mean, rstd=rstd)
+        return xv, out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        model = ctx.model
+        rt = model.runtime()
+        c = rt._ctx
+        M, C = c["M"], rt.C
+        dout = grads[0] if ctx.clip_only else grads[1]
+        dxv = None if ctx.clip_only else grads[0]
+        lnws = rt.ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(rt.D, C)))
+        for k in range(len(rt.taps)):
+            d = rt.dec[k]
+            dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
+            if dout is None:
+                dy.zero_()
+                continue
+            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout[k].contiguous().view(M, C), dy,
+                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate)
+        rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D))
+        return None, None, None, None, None, None
+
+
+class _StudentLossFn(torch.autograd.Function):
+    """Fused decoder tail + UMT loss (run_stage1.py:431); backward needs no d(x_clip) tensor."""
+
+    @staticmethod
+    def forward(ctx, model, videos, vis_tokens, n_vis, targets, anchor):
+        rt = model.runtime()
+        ys, _ = rt.forward_features(videos, vis_tokens, n_vis, True, model.training)
+        M, C, K = videos.shape[0] * n_vis, rt.C, len(rt.taps)
+        loss_sum = rt.ws.get("loss.sum", (1,), F32)
+        loss_sum.zero_()
+        tg = targets.view(K, M, C)
+        for k in range(K):
+            d = rt.dec[k]
+            ops.decoder_tail_fwd(ys[k], d["nw"], d["nb"], model.ln_eps, tg[k], None, loss_sum)
+        ctx.model, ctx.targets = model, tg
+        return loss_sum[0] / float(K * M)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model = ctx.model
+        rt = model.runtime()
+        c = rt._ctx
+        M, C, K = c["M"], rt.C, len(rt.taps)
+        lnws = rt.ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(rt.D, C)))
+        g = gloss.contiguous().to(F32)
+        for k in range(K):
+            d = rt.dec[k]
+            dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
+            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, ctx.targets[k], 1.0 / float(K * M), None, dy,
+                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, loss_scale_dev=g)
+        rt.backward_from_dy(None)
+        return None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- factories (reference :337-378)
+@register_model
+def adaptation_umt_base_patch16_224(pretrained=False, **kwargs):
+    kwargs.pop("drop_block_rate", None)
+    init_ckpt = kwargs.pop("init_ckpt", None)
+    model = AdaptationVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=768, encoder_depth=12,
+                                        encoder_num_heads=12, encoder_num_classes=0, mlp_ratio=4, qkv_bias=True,
+                                        norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    if pretrained:
+        model.load_state_dict(torch.load(init_ckpt, map_location="cpu", weights_only=True)["model"])
+    return model
+
+
+@register_model
+def adaptation_umt_large_patch16_224(pretrained=False, **kwargs):
+    kwargs.pop("drop_block_rate", None)
+    init_ckpt = kwargs.pop("init_ckpt", None)
+    model = AdaptationVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=1024, encoder_depth=24,
+                                        encoder_num_heads=16, encoder_num_classes=0, mlp_ratio=4, qkv_bias=True,
+                                        norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    if pretrained:
+        model.load_state_dict(torch.load(init_ckpt, map_location="cpu", weights_only=True)["model"])
+    return model

@@ -167,19 +167,26 @@ def l2_normalize_rows(x):
     return x
 
 
-def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int):
+def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int, vis_rows_cls=None):
     lib = _lib.load()
     BT, N = weights.shape
-    _lib.check(lib.unite_mask_sample(_ptr(weights), seed & 0xFFFFFFFFFFFFFFFF, _ptr(mask), _ptr(vis_tokens), BT, N, n_vis, _stream()),
-               "unite_mask_sample")
+    _lib.check(lib.unite_mask_sample(_ptr(weights), seed & 0xFFFFFFFFFFFFFFFF, _ptr(mask), _ptr(vis_tokens), _ptr(vis_rows_cls),
+                                     BT, N, n_vis, _stream()), "unite_mask_sample")
 
 
-def mask_from_importance(importance, mask, vis_tokens, n_vis: int):
+def mask_from_importance(importance, mask, vis_tokens, n_vis: int, vis_rows_cls=None):
     lib = _lib.load()
     BT, N = importance.shape
     assert importance.dtype == torch.int64 and importance.is_contiguous()
-    _lib.check(lib.unite_mask_from_importance(_ptr(importance), _ptr(mask), _ptr(vis_tokens), BT, N, n_vis, _stream()),
-               "unite_mask_from_importance")
+    _lib.check(lib.unite_mask_from_importance(_ptr(importance), _ptr(mask), _ptr(vis_tokens), _ptr(vis_rows_cls), BT, N, n_vis,
+                                              _stream()), "unite_mask_from_importance")
+
+
+def mask_to_tokens(mask_u8, vis_tokens, n_vis: int, BT: int, N: int, vis_rows_cls=None):
+    lib = _lib.load()
+    assert mask_u8.dtype == torch.uint8 and mask_u8.is_contiguous()
+    _lib.check(lib.unite_mask_to_tokens(_ptr(mask_u8), _ptr(vis_tokens), _ptr(vis_rows_cls), BT, N, n_vis, _stream()),
+               "unite_mask_to_tokens")
 
 
 def decoder_tail_fwd(y, gamma, beta, eps: float, tgt, out, loss_sum):
@@ -190,10 +197,10 @@ def decoder_tail_fwd(y, gamma, beta, eps: float, tgt, out, loss_sum):
 
 
 def decoder_tail_bwd(y, gamma, beta, eps: float, tgt, loss_scale: float, dout, dy_bf16, dgamma, dbeta, workspace,
-                     accumulate: bool = False):
+                     accumulate: bool = False, loss_scale_dev=None):
     lib = _lib.load()
     M, Cd = y.shape
-    _lib.check(lib.unite_decoder_tail_bwd(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(tgt), loss_scale, _ptr(dout), _ptr(dy_bf16),
+    _lib.check(lib.unite_decoder_tail_bwd(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(tgt), loss_scale, _ptr(loss_scale_dev), _ptr(dout), _ptr(dy_bf16),
                                           _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace), M, Cd, _stream()),
                "unite_decoder_tail_bwd")
 

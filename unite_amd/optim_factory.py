@@ -1,0 +1,206 @@
+"""Optimizer construction -- drop-in for reference src/optim_factory.py (AdamW path, the only one any UNITE config
+selects: ``opt: adamw`` in configs/stage{1,2,3}_config.yaml).
+
+``create_optimizer`` keeps the reference's signature, parameter grouping (no_decay for 1-D tensors / ``.bias`` /
+``no_weight_decay()`` names, optional ``layer_{id}_`` split with ``lr_scale``) and returns a ``torch.optim.Optimizer``
+subclass whose ``param_groups`` the engines edit exactly as before (run_stage1.py:326-338).  ``step()`` is ONE launch
+of ``unite_adamw_flat`` over the model's flat parameter buffer, which also refreshes the bf16 weights the GEMMs read.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .flat_params import FlatParams
+
+
+def get_num_layer_for_vit(var_name, num_max_layer):
+    """reference optim_factory.py:44-62 (note: 'encoder.blocks.*' names fall through to the last id, SURVEY A-7)."""
+    if var_name in ("cls_token", "mask_token", "pos_embed"):
+        return 0
+    elif var_name.startswith("patch_embed"):
+        return 0
+    elif var_name.startswith("rel_pos_bias"):
+        return num_max_layer - 1
+    elif var_name.startswith("blocks"):
+        return int(var_name.split('.')[1]) + 1
+    elif var_name.startswith("transformer.resblocks"):
+        return int(var_name.split('.')[2]) + 1
+    elif var_name in ("class_embedding", "positional_embedding", "temporal_positional_embedding"):
+        return 0
+    elif var_name.startswith("conv1"):
+        return 0
+    else:
+        return num_max_layer - 1
+
+
+class LayerDecayValueAssigner(object):
+    def __init__(self, values):
+        self.values = values
+
+    def get_scale(self, layer_id):
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name):
+        return get_num_layer_for_vit(var_name, len(self.values))
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None, with_names=False):
+    """reference optim_factory.py:76-118; group order = first appearance in named_parameters()."""
+    names: Dict[str, dict] = {}
+    groups: Dict[str, dict] = {}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            group_name, this_wd = "no_decay", 0.
+        else:
+            group_name, this_wd = "decay", weight_decay
+        layer_id = None
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            group_name = "layer_%d_%s" % (layer_id, group_name)
+        if group_name not in groups:
+            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.
+            groups[group_name] = {"weight_decay": this_wd, "params": [], "lr_scale": scale}
+            names[group_name] = {"weight_decay": this_wd, "params": [], "lr_scale": scale}
+        groups[group_name]["params"].append(param)
+        names[group_name]["params"].append(name)
+    if with_names:
+        return list(groups.values()), list(names.values())
+    return list(groups.values())
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) in one kernel launch per step."""
+
+    def __init__(self, params, flat: Optional[FlatParams], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        for g in self.param_groups:
+            g.setdefault("lr_scale", 1.0)
+        if len(self.param_groups) > 64:
+            raise ValueError("unite_adamw_flat supports at most 64 parameter groups")
+        self._flat = flat
+        self._step = 0
+        self._ready = False
+
+    def attach(self, flat: FlatParams):
+        self._flat = flat
+
+    def _prepare(self):
+        fp = self._flat
+        if fp is None:
+            raise RuntimeError("FusedAdamW is not attached to a flat parameter buffer (call model.runtime() first)")
+        name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
+        group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                group_of[name_of[id(p)]] = gi
+        missing = [n for n in fp.names if n not in group_of]
+        if missing:
+            # parameters outside the optimizer (frozen / filtered): give them a zero-lr group
+            if len(self.param_groups) >= 64:
+                raise ValueError("no spare group for parameters that are not optimised")
+            self._frozen_group = len(self.param_groups)
+            for n in missing:
+                group_of[n] = self._frozen_group
+        else:
+            self._frozen_group = None
+        self._chunk_group = fp.chunk_groups(group_of)
+        self.exp_avg = torch.zeros_like(fp.param)
+        self.exp_avg_sq = torch.zeros_like(fp.param)
+        self._ready = True
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
+        if not self._ready:
+            self._prepare()
+        fp = self._flat
+        self._step += 1
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        wds = [float(g["weight_decay"]) for g in self.param_groups]
+        if self._frozen_group is not None:
+            lrs.append(0.0)
+            wds.append(0.0)
+        b1, b2 = self.param_groups[0]["betas"]
+        ops.adamw_flat(fp.param, fp.grad, self.exp_avg, self.exp_avg_sq, fp.shadow, self._chunk_group, lrs, wds,
+                       float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step, grad_scale=grad_scale, found_inf=found_inf)
+
+    def zero_grad(self, set_to_none: bool = True):
+        """The next backward overwrites the flat gradient buffer instead of adding to it: no 352 MB memset."""
+        if self._flat is not None:
+            self._flat.accumulate = False
+            self._flat.ensure_grad_views()
+
+    # checkpoint layout compatible with torch.optim.AdamW ({'state': {idx: {step, exp_avg, exp_avg_sq}}, 'param_groups'})
+    def state_dict(self):
+        if not self._ready:
+            self._prepare()
+        fp = self._flat
+        pid, state, groups = {}, {}, []
+        i = 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                pid[id(p)] = i
+                ids.append(i)
+                i += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
+        for g in self.param_groups:
+            for p in g["params"]:
+                o, k = fp.offsets[name_of[id(p)]]
+                state[pid[id(p)]] = {"step": torch.tensor(float(self._step)),
+                                     "exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                                     "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        if not self._ready:
+            self._prepare()
+        fp = self._flat
+        name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
+        i = 0
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+            for p in g["params"]:
+                st = sd["state"].get(i)
+                if st is not None:
+                    o, k = fp.offsets[name_of[id(p)]]
+                    self.exp_avg[o:o + k].view(p.shape).copy_(st["exp_avg"])
+                    self.exp_avg_sq[o:o + k].view(p.shape).copy_(st["exp_avg_sq"])
+                    self._step = int(float(st["step"]))
+                i += 1
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    """reference optim_factory.py:121-211, AdamW/Adam branches."""
+    opt_lower = args.opt.lower()
+    weight_decay = args.weight_decay
+    if weight_decay and filter_bias_and_bn:
+        skip = {}
+        if skip_list is not None:
+            skip = skip_list
+        elif hasattr(model, 'no_weight_decay'):
+            skip = model.no_weight_decay()
+        parameters = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale)
+        weight_decay = 0.
+    else:
+        parameters = [p for p in model.parameters() if p.requires_grad]
+    opt_args = dict(lr=args.lr, weight_decay=weight_decay)
+    if getattr(args, 'opt_eps', None) is not None:
+        opt_args['eps'] = args.opt_eps
+    if getattr(args, 'opt_betas', None) is not None:
+        opt_args['betas'] = args.opt_betas
+    print("optimizer settings:", opt_args)
+    name = opt_lower.split('_')[-1]
+    if name not in ("adamw", "fusedadamw"):
+        raise NotImplementedError(f"optimizer '{args.opt}': only the AdamW branch of the reference factory is built "
+                                  "(all UNITE configs use opt: adamw)")
+    flat = model.runtime().fp if hasattr(model, "runtime") else None
+    return FusedAdamW(parameters, flat, **opt_args)

@@ -1,0 +1,311 @@
+"""Host-side helpers the engines call -- the hot subset of reference src/utils.py with the same names and call
+signatures: loss scaler facade, gradient norm, schedules, meters, distributed
+init, checkpoint dict layout.  Device work goes through unite_amd.ops (C ABI); nothing here computes on ATen
+in the per-step path except reading scalars back at log time.
+"""
+from __future__ import annotations
+
+import datetime
+import math
+import os
+import time
+from collections import defaultdict, deque
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- scaler / grad norm (utils.py:602-643)
+class NativeScalerWithGradNormCount:
+    """Same call signature and state_dict()['scale'] as the reference (utils.py:602-628).  The kernels compute in
+    bf16 operands / fp32 accumulation, so there is no loss scaling: scale is the constant 1.0 (SURVEY A-17)."""
+    state_dict_key = "amp_scaler"
+
+    def __init__(self):
+        self._scale = 1.0
+        self._norm = None
+        self._coef = None
+        self._ws = None
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True, reducer=None):
+        loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if reducer is not None:
+            reducer.finish()                          # join the gradient all-reduce (side stream) before reading grads
+        flat = getattr(optimizer, "_flat", None)
+        if flat is None:
+            raise RuntimeError("optimizer is not a unite_amd FusedAdamW bound to a flat parameter buffer")
+        norm = self.grad_norm(flat, clip_grad)
+        optimizer.step(grad_scale=self._coef if (clip_grad is not None and clip_grad > 0) else None)
+        return norm
+
+    def grad_norm(self, flat, clip_grad=None):
+        dev = flat.grad.device
+        if self._norm is None:
+            self._norm = torch.zeros(1, device=dev)
+            self._coef = torch.ones(1, device=dev)
+            self._ws = torch.empty(ops.grad_norm_workspace(flat.grad.numel()), dtype=torch.uint8, device=dev)
+        ops.grad_norm_flat(flat.grad, self._norm, self._ws, max_norm=float(clip_grad or 0.0), clip_coef_out=self._coef)
+        return self._norm[0]                          # 0-dim device tensor: no host sync here
+
+    def state_dict(self):
+        return {"scale": self._scale}
+
+    def load_state_dict(self, state_dict):
+        self._scale = 1.0
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """utils.py:631-643 for models on a flat buffer: sqrt(sum of squares) in one reduction."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    if len(parameters) == 0:
+        return torch.tensor(0.)
+    if norm_type != 2.0:
+        raise NotImplementedError("only the L2 norm is built")
+    dev = parameters[0].grad.device
+    out = torch.zeros(1, device=dev)
+    sq = torch.zeros(1, device=dev)
+    ws = None
+    total = None
+    for p in parameters:       # generic (non-flat) path: one reduction per tensor, combined on device
+        g = p.grad.contiguous().view(-1)
+        if ws is None or ws.numel() < ops.grad_norm_workspace(g.numel()):
+            ws = torch.empty(ops.grad_norm_workspace(g.numel()), dtype=torch.uint8, device=dev)
+        ops.grad_norm_flat(g, out, ws)
+        total = out * out if total is None else total + out * out
+    return total.sqrt()[0]
+
+
+# ----------------------------------------------------------------------------- schedules (utils.py:646-686)
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
+    warmup_schedule = np.array([])
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    print("Set warmup steps = %d" % warmup_iters)
+    if warmup_epochs > 0:
+        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / (len(iters)))) for i in iters])
+    schedule = np.concatenate((warmup_schedule, schedule))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def step_scheduler(base_value, step_fraction, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1, steps=None):
+    warmup_schedule = np.array([])
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    if warmup_epochs > 0:
+        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    if steps is None:
+        schedule = np.ones(epochs * niter_per_ep - warmup_iters) * base_value
+    else:
+        schedule = np.ones(epochs * niter_per_ep)
+        for i in range(len(steps)):
+            schedule[steps[i] * niter_per_ep:] *= step_fraction[i]
+    schedule = np.concatenate((warmup_schedule, schedule))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def get_greedy_masks(attn, mask_ratio, k):
+    """utils.py:89-120: committee member i unmasks attention ranks i, i+k, ... ; bool (k, BT, N), True = masked.
+    (stage 3; index bookkeeping on the device through torch's sort -- not on the stage-1 hot path.)"""
+    BT, N = attn.shape
+    n_unmask = N - int(N * mask_ratio)
+    _, order = attn.sort(dim=1, descending=True)
+    masks = torch.ones((k, BT, N), dtype=torch.bool, device=attn.device)
+    for i in range(k):
+        masks[i].scatter_(1, order[:, i::k][:, :n_unmask], False)
+    return masks
+
+
+# ----------------------------------------------------------------------------- meters (utils.py:215-423)
+class SmoothedValue(object):
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self.total, self.count = 0.0, 0
+        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        if not is_dist_avail_and_initialized():
+            return
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        t = t.tolist()
+        self.count, self.total = int(t[0]), t[1]
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return self.total / max(self.count, 1)
+
+    @property
+    def max(self):
+        return max(self.deque)
+
+    @property
+    def value(self):
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger(object):
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            self.meters[k].update(float(v))
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        raise AttributeError(attr)
+
+    def __str__(self):
+        return self.delimiter.join("{}: {}".format(n, str(m)) for n, m in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for meter in self.meters.values():
+            meter.synchronize_between_processes()
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, n_epochs=None, epoch=None, ipe=None, header=None):
+        i = 0
+        header = header or ''
+        start = time.time()
+        end = time.time()
+        iter_time, data_time = SmoothedValue(fmt='{avg:.4f}'), SmoothedValue(fmt='{avg:.4f}')
+        n = len(iterable)
+        for obj in iterable:
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if print_freq and (i % print_freq == 0 or i == n - 1):
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
+                print(self.delimiter.join([header, f"[{i}/{n}]", f"eta: {eta}", str(self), f"time: {iter_time}", f"data: {data_time}"]))
+            i += 1
+            end = time.time()
+        total = time.time() - start
+        print('{} Total time: {} ({:.4f} s / it)'.format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+
+
+# ----------------------------------------------------------------------------- distributed (utils.py:450-551)
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def init_distributed_mode(args):
+    """env:// rendezvous as torchrun provides it (utils.py:532-551); backend 'nccl' is RCCL on ROCm."""
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ['WORLD_SIZE'])
+        args.gpu = int(os.environ['LOCAL_RANK'])
+    else:
+        print('Not using distributed mode')
+        args.distributed = False
+        return
+    args.distributed = True
+    backend = getattr(args, "dist_backend", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(args.gpu)
+    print('| distributed init (rank {}): {}, gpu {}'.format(args.rank, getattr(args, "dist_url", "env://"), args.gpu), flush=True)
+    dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size, rank=args.rank)
+    if backend == "nccl":
+        dist.barrier(device_ids=[args.gpu])
+    else:
+        dist.barrier()
+
+
+# ----------------------------------------------------------------------------- checkpoints (utils.py:689-776)
+def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None, tag=None):
+    """{'model','optimizer','epoch','scaler','args'} in checkpoint-{epoch|tag}.pth on rank 0 (utils.py:689-736)."""
+    output_dir = Path(args.output_dir)
+    path = output_dir / ('checkpoint-%s.pth' % (tag if tag is not None else str(epoch)))
+    to_save = {'model': model_without_ddp.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch,
+               'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}
+    save_on_master(to_save, path)
+    return path
+
+
+def save_latest_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None, model_name='latest'):
+    return save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema, tag=model_name)
+
+
+def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """prefers checkpoint-latest.pth, then -best, then the highest epoch number (utils.py:739-776)."""
+    output_dir = Path(args.output_dir)
+    if getattr(args, "auto_resume", False) and len(getattr(args, "resume", "")) == 0:
+        import glob
+        if (output_dir / 'checkpoint-latest.pth').exists():
+            args.resume = str(output_dir / 'checkpoint-latest.pth')
+        elif (output_dir / 'checkpoint-best.pth').exists():
+            args.resume = str(output_dir / 'checkpoint-best.pth')
+        else:
+            latest = -1
+            for ckpt in glob.glob(os.path.join(output_dir, 'checkpoint-*.pth')):
+                t = ckpt.split('-')[-1].split('.')[0]
+                if t.isdigit():
+                    latest = max(int(t), latest)
+            if latest >= 0:
+                args.resume = os.path.join(output_dir, 'checkpoint-%d.pth' % latest)
+    if getattr(args, "resume", ""):
+        ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)   # a file this code wrote
+        model_without_ddp.load_state_dict(ckpt['model'])
+        if 'optimizer' in ckpt and 'epoch' in ckpt:
+            optimizer.load_state_dict(ckpt['optimizer'])
+            args.start_epoch = ckpt['epoch'] + 1
+            if 'scaler' in ckpt:
+                loss_scaler.load_state_dict(ckpt['scaler'])
+        print("Resume checkpoint %s" % args.resume)

@@ -1,0 +1,228 @@
+"""Hand-scheduled forward / backward of the video ViT on the C-ABI kernels (no autograd tape, no ATen compute).
+
+One ``ViTRunner`` drives the encoder of both student-style models:
+  * stage 1/3 student: AdaptationVisionTransformer  (reference src/models/modeling_adaptation.py:131-179,304-334)
+  * stage 2 classifier: VisionTransformer            (reference src/models/modeling_finetune.py:356-383)
+Per block (reference Block.forward, modeling_finetune.py:143-146) the launches are
+  LN1 -> GEMM qkv(+q/v bias) -> fused attention -> GEMM proj(+bias, drop-path scale, +residual)
+  LN2 -> GEMM fc1(+bias, GELU, keeps pre-activation) -> GEMM fc2(+bias, drop-path scale, +residual)
+and the backward mirrors them with dgrad (NN) / wgrad (TN) GEMMs writing fp32 gradients straight into the flat
+gradient buffer.  The residual stream and its gradient stay fp32; GEMM operands are bf16.
+Activations needed by the backward are kept in HBM (about 283 MB per block at B=32: 288 GB makes
+recomputation pointless).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .flat_params import FlatParams
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Workspace:
+    """Named device buffers reused across steps (shapes are static in training)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype) -> torch.Tensor:
+        t = self.bufs.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        return t
+
+    def bytes_(self, name: str, nbytes: int) -> torch.Tensor:
+        t = self.bufs.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self.bufs[name] = t
+        return t
+
+
+class ViTRunner:
+    def __init__(self, fp: FlatParams, prefix: str, embed_dim: int, depth: int, num_heads: int, mlp_hidden: int,
+                 ln_eps: float, patch_size: int, num_patches: int, pos_table: torch.Tensor, drop_path_rates: Sequence[float]):
+        if embed_dim != num_heads * 64:
+            raise NotImplementedError("the gfx950 attention kernels are built for head_dim 64")
+        self.fp, self.pre = fp, prefix
+        self.D, self.depth, self.H, self.Hd = embed_dim, depth, num_heads, mlp_hidden
+        self.eps, self.P, self.num_patches = ln_eps, patch_size, num_patches
+        self.pos_table = pos_table              # f32 [num_patches, D] on device (not a parameter, modeling_adaptation.py:91)
+        self.dp_rates = list(drop_path_rates)
+        self.ws = Workspace(fp.device)
+        self.saved: List[dict] = []
+        self.scale = 64 ** -0.5                 # head_dim ** -0.5 (modeling_finetune.py:86)
+
+    # ------------------------------------------------------------------ helpers
+    def _p(self, name):
+        return self.fp.params[self.fp.names.index(self.pre + name)].data
+
+    def _w(self, name):
+        return self.fp.w16(self.pre + name)
+
+    def _g(self, name):
+        return self.fp.g(self.pre + name)
+
+    def _cache_names(self):
+        # resolve parameter tensors once (name lookups are off the hot path afterwards)
+        if hasattr(self, "_blk"):
+            return
+        fp, pre = self.fp, self.pre
+        idx = {n: i for i, n in enumerate(fp.names)}
+
+        def P(n):
+            return fp.params[idx[pre + n]].data
+
+        self._blk = []
+        for i in range(self.depth):
+            b = f"blocks.{i}."
+            d = {}
+            for n in ["norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                      "mlp.fc1.bias", "mlp.fc2.bias"]:
+                d[n] = P(b + n)
+                d["g:" + n] = fp.g(pre + b + n)
+            for n in ["attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"]:
+                d[n] = fp.w16(pre + b + n)
+                d["g:" + n] = fp.g(pre + b + n)
+            d["qkv_bias"] = fp.packed_qkv_bias(pre + b + "attn.")        # (q_bias, 0, v_bias), modeling_finetune.py:104
+            self._blk.append(d)
+        self._pe_w = fp.w16(pre + "patch_embed.proj.weight")
+        self._pe_b = P("patch_embed.proj.bias")
+        self._pe_gw = fp.g(pre + "patch_embed.proj.weight")
+        self._pe_gb = fp.g(pre + "patch_embed.proj.bias")
+
+    def drop_path_scales(self, B: int, training: bool) -> Optional[torch.Tensor]:
+        """(depth, 2, B) f32 multipliers floor(keep + U)/keep (timm drop_path as used at modeling_finetune.py:50), or None."""
+        if not training or max(self.dp_rates) == 0.0:
+            return None
+        keep = 1.0 - torch.tensor(self.dp_rates, dtype=F32, device=self.fp.device).view(-1, 1, 1)
+        u = torch.rand(self.depth, 2, B, dtype=F32, device=self.fp.device)
+        return torch.floor(keep + u) / keep
+
+    # ------------------------------------------------------------------ forward
+    def embed(self, videos: torch.Tensor, tokens: Optional[torch.Tensor], M: int) -> torch.Tensor:
+        """patch-embed GEMM on the listed tokens + bias + sinusoid position rows -> x0 f32 [M, D]."""
+        self._cache_names()
+        D, ws = self.D, self.ws
+        Kpe = 3 * self.P * self.P
+        if videos.shape[1] != 3 or videos.dtype != F32:
+            raise ValueError("videos must be float32 (B,3,T,H,W)")
+        cols = ws.get("pe.cols", (M, Kpe), BF16)
+        ops.im2col_gather(videos.contiguous(), tokens, cols, self.P)
+        pos = ws.get("pe.pos", (M, D), F32)
+        ops.gather_rows(self.pos_table, tokens, pos, modulo=self.num_patches)
+        x0 = ws.get("x.0", (M, D), F32)
+        ops.gemm(cols, self._pe_w.view(D, Kpe), x0, bias=self._pe_b, residual=pos)
+        return x0
+
+    def blocks_forward(self, x0: torch.Tensor, B: int, N: int, n_blocks: int, dp: Optional[torch.Tensor], save: bool) -> List[torch.Tensor]:
+        """Runs blocks 0..n_blocks-1; returns [x0, x_out(0), ..., x_out(n_blocks-1)] (f32 [M, D] each)."""
+        self._cache_names()
+        D, H, Hd, ws = self.D, self.H, self.Hd, self.ws
+        M = B * N
+        xs = [x0]
+        self.saved = []
+        x = x0
+        for i in range(n_blocks):
+            w = self._blk[i]
+            t = f"b{i}." if save else "t."          # without save, activations share one set of buffers
+            h1 = ws.get(t + "h1", (M, D), BF16)
+            mean1, rstd1 = ws.get(t + "mean1", (M,), F32), ws.get(t + "rstd1", (M,), F32)
+            ops.layernorm_fwd(x, w["norm1.weight"], w["norm1.bias"], self.eps, h1, mean=mean1, rstd=rstd1)
+            qkv = ws.get(t + "qkv", (M, 3 * D), BF16)
+            ops.gemm(h1, w["attn.qkv.weight"], qkv, bias=w["qkv_bias"])
+            o = ws.get(t + "o", (M, D), BF16)
+            lse = ws.get(t + "lse", (B, H, N), F32)
+            ops.attn_fwd(qkv, o, lse, B, N, H, self.scale)
+            x1 = ws.get(t + "x1", (M, D), F32)
+            ops.gemm(o, w["attn.proj.weight"], x1, bias=w["attn.proj.bias"], residual=x,
+                     row_scale=None if dp is None else dp[i, 0], rows_per_scale=N)
+            h2 = ws.get(t + "h2", (M, D), BF16)
+            mean2, rstd2 = ws.get(t + "mean2", (M,), F32), ws.get(t + "rstd2", (M,), F32)
+            ops.layernorm_fwd(x1, w["norm2.weight"], w["norm2.bias"], self.eps, h2, mean=mean2, rstd=rstd2)
+            z = ws.get(t + "z", (M, Hd), BF16) if save else None
+            a = ws.get(t + "a", (M, Hd), BF16)
+            ops.gemm(h2, w["mlp.fc1.weight"], a, bias=w["mlp.fc1.bias"], act=ops.ACT_GELU, aux_out=z)
+            x2 = ws.get(f"x.{i + 1}" if save else f"t.x{(i + 1) & 1}", (M, D), F32)
+            ops.gemm(a, w["mlp.fc2.weight"], x2, bias=w["mlp.fc2.bias"], residual=x1,
+                     row_scale=None if dp is None else dp[i, 1], rows_per_scale=N)
+            if save:
+                self.saved.append(dict(x_in=x, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2,
+                                       mean2=mean2, rstd2=rstd2, z=z, a=a))
+            xs.append(x2)
+            x = x2
+        self._fw = dict(B=B, N=N, dp=dp)
+        return xs
+
+    # ------------------------------------------------------------------ backward
+    def blocks_backward(self, dx: torch.Tensor, dxb: torch.Tensor, n_blocks: int, tap_hook=None, layer_done=None):
+        """dx: f32 [M,D] gradient w.r.t. x_out(n_blocks-1); dxb: its bf16 copy already multiplied by the
+        drop-path scale of that block's MLP branch.  tap_hook(i, dx, dxb_out, scale) is called when the gradient
+        w.r.t. x_out(i-1) is complete except for a tap contribution (it must add it and return the final (dx, dxb)).
+        Writes every block's parameter gradients; returns (dx0 f32, dx0 bf16 unscaled) w.r.t. the block-0 input."""
+        fw = self._fw
+        B, N, dp = fw["B"], fw["N"], fw["dp"]
+        D, H, Hd, ws, fp = self.D, self.H, self.Hd, self.ws, self.fp
+        M = B * N
+        acc = fp.accumulate
+        lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
+        csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
+        for i in reversed(range(n_blocks)):
+            w, s = self._blk[i], self.saved[i]
+            # ---- MLP branch
+            dz = ws.get("bw.dz", (M, Hd), BF16)
+            ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
+            ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.colsum(dxb, w["g:mlp.fc2.bias"], csws, accumulate=acc)
+            dh2 = ws.get("bw.dh", (M, D), BF16)
+            ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
+            ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
+            dx1 = ws.get("bw.dx1", (M, D), F32)
+            dx1b = ws.get("bw.dx1b", (M, D), BF16)
+            ops.layernorm_bwd(dh2, s["x1"], s["mean2"], s["rstd2"], w["norm2.weight"], dx_residual=dx, dx_out=dx1, dx_bf16=dx1b,
+                              row_scale=None if dp is None else dp[i, 0], rows_per_scale=N,
+                              dgamma=w["g:norm2.weight"], dbeta=w["g:norm2.bias"], accumulate=acc, workspace=lnws)
+            # ---- attention branch
+            do = ws.get("bw.do", (M, D), BF16)
+            ops.gemm(dx1b, w["attn.proj.weight"], do, trans_b=True)
+            ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.colsum(dx1b, w["g:attn.proj.bias"], csws, accumulate=acc)
+            dqkv = ws.get("bw.dqkv", (M, 3 * D), BF16)
+            delta = ws.get("bw.delta", (B, H, N), F32)
+            ops.attn_bwd(s["qkv"], s["o"], do, s["lse"], delta, dqkv, B, N, H, self.scale)
+            dh1 = ws.get("bw.dh", (M, D), BF16)
+            ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
+            ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.colsum(dqkv[:, :D], w["g:attn.q_bias"], csws, accumulate=acc)
+            ops.colsum(dqkv[:, 2 * D:], w["g:attn.v_bias"], csws, accumulate=acc)
+            # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
+            # branch's drop-path factor) or the patch-embed weight gradient (unscaled)
+            dx0 = ws.get(f"bw.dx{i & 1}", (M, D), F32)
+            dx0b = ws.get("bw.dxb", (M, D), BF16)
+            nxt_scale = None if (dp is None or i == 0) else dp[i - 1, 1]
+            ops.layernorm_bwd(dh1, s["x_in"], s["mean1"], s["rstd1"], w["norm1.weight"], dx_residual=dx1, dx_out=dx0, dx_bf16=dx0b,
+                              row_scale=nxt_scale, rows_per_scale=N,
+                              dgamma=w["g:norm1.weight"], dbeta=w["g:norm1.bias"], accumulate=acc, workspace=lnws)
+            dx, dxb = dx0, dx0b
+            if tap_hook is not None and i > 0:
+                dx, dxb = tap_hook(i - 1, dx, dxb, nxt_scale)
+            if layer_done is not None:
+                layer_done(i)
+        return dx, dxb
+
+    def embed_backward(self, dxb: torch.Tensor):
+        """patch-embed weight/bias gradients from the bf16 gradient w.r.t. x0 (no input gradient: the clip is data)."""
+        ws, fp, D = self.ws, self.fp, self.D
+        cols = ws.bufs["pe.cols"]
+        M = cols.shape[0]
+        csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(self.Hd, 3 * D)))
+        ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate)
+        ops.colsum(dxb, self._pe_gb, csws, accumulate=fp.accumulate)
