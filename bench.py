@@ -37,7 +37,12 @@ def cpu_baseline(seconds_budget=25.0):
     from oracle import umt_oracle as O
     from oracle.filler import fill_state_dict, make_importance, make_videos
     from tests.shapes import student_shapes, teacher_shapes
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-CPU share whatever os.cpu_count() says: oversubscribing it stalls for minutes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("UNITE_CPU_THREADS", 16))))
     torch.set_num_threads(threads)
     scfg, tcfg = O.StudentCfg(), O.TeacherCfg()
     ssd = fill_state_dict(student_shapes(scfg), 12)
@@ -62,6 +67,7 @@ def cpu_baseline(seconds_budget=25.0):
     t0 = time.time()
     step(1)                                   # warm-up
     warm = time.time() - t0
+    print(f"[bench] cpu baseline warm-up step: {warm:.1f} s on {threads} threads", file=sys.stderr, flush=True)
     n = max(1, min(6, int((seconds_budget - warm) / max(warm, 1e-3))))
     t0 = time.time()
     for i in range(n):
@@ -151,6 +157,8 @@ def main():
         dt = float(t.item())
     loss_v, gn_v = float(loss.item()), float(gn.item())
     ms_step = dt / a.steps * 1e3
+    if rank == 0:
+        print(f"[bench] timed region: {a.steps} steps in {dt:.3f} s ({dt / a.steps * 1e3:.2f} ms/step), loss {loss_v:.4f}", file=sys.stderr, flush=True)
     clips_s = total_batch * a.steps / dt
 
     roof = None
@@ -165,6 +173,7 @@ def main():
         ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
         lib.unite_prof_summary(C.byref(ms), C.byref(cnt), C.byref(fl))
         lib.unite_prof_enable(0, 0)
+        print(f"[bench] profiled pass: {cnt.value} GEMM launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12,
                 "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None,
