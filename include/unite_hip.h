@@ -67,6 +67,9 @@ typedef struct unite_gemm_args {
     const float* residual;  int32_t ldr;
     void* out; int32_t ldc; int32_t out_f32; int32_t accumulate;
     void* out_bf16_copy; int32_t ld_copy;
+    void* workspace; int64_t workspace_bytes;   /* optional scratch (16-byte aligned): lets short-and-wide products with a plain
+                                                   f32 output (weight gradients) run split-K through f32 slabs [S][M][N],
+                                                   summed in a fixed order (bitwise reproducible); NULL = never split */
 } unite_gemm_args;
 
 int unite_gemm_bf16(const unite_gemm_args* args, void* stream);

@@ -52,6 +52,29 @@ def test_gemm_exact_integers(ops, ta, tb, M, N, K):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 10240), (3072, 768, 2560), (136, 264, 1100)])
+def test_gemm_splitk_weight_gradient(ops, M, N, K):
+    """TN product with a workspace: split-K through f32 slabs, fixed summation order (bit-reproducible), exact on integers."""
+    g = torch.Generator().manual_seed(K)
+    a = torch.randint(-3, 4, (K, M), generator=g).float()
+    b = torch.randint(-3, 4, (K, N), generator=g).float()
+    ref = (a.double().t() @ b.double()).float()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(bf(a).to(DEV), bf(b).to(DEV), out, trans_a=True, trans_b=True, workspace=ws)
+    assert torch.equal(out.cpu(), ref)
+    base = torch.randint(-5, 6, (M, N), generator=g).float()
+    out.copy_(base.to(DEV))
+    ops.gemm(bf(a).to(DEV), bf(b).to(DEV), out, trans_a=True, trans_b=True, workspace=ws, accumulate=True)
+    assert torch.equal(out.cpu(), ref + base)
+    x = torch.randn(K, M, generator=g); y = torch.randn(K, N, generator=g)
+    o1 = torch.empty(M, N, dtype=torch.float32, device=DEV); o2 = torch.empty_like(o1)
+    ops.gemm(bf(x).to(DEV), bf(y).to(DEV), o1, trans_a=True, trans_b=True, workspace=ws)
+    ops.gemm(bf(x).to(DEV), bf(y).to(DEV), o2, trans_a=True, trans_b=True, workspace=ws)
+    assert torch.equal(o1, o2)
+    torch.testing.assert_close(o1.cpu(), bf(x).float().t() @ bf(y).float(), atol=2e-3, rtol=1e-4)
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 330, 264, 192
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))

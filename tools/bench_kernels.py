@@ -7,6 +7,7 @@ import torch
 from unite_amd import ops
 
 DEV = "cuda"
+WS = torch.empty(200 << 20, dtype=torch.uint8, device=DEV)
 
 
 def timeit(fn, iters=20, warm=3):
@@ -26,6 +27,8 @@ def gemm_case(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, **kw)
     a = torch.randn((K, M) if ta else (M, K), device=DEV).to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device=DEV).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=out_dtype, device=DEV)
+    if ta and tb:
+        kw["workspace"] = WS
     t = timeit(lambda: ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw))
     fl = 2.0 * M * N * K
     print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} ta={int(ta)} tb={int(tb)}  {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TF/s  {fl/t/2.5e15*100:5.1f}% peak", flush=True)

@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("residual", c_p), ("ldr", c_i),
         ("out", c_p), ("ldc", c_i), ("out_f32", c_i), ("accumulate", c_i),
         ("out_bf16_copy", c_p), ("ld_copy", c_i),
+        ("workspace", c_p), ("workspace_bytes", c_i64),
     ]
 
 

@@ -29,6 +29,8 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 64 KiB  (epilogue image: 64 
 struct Params {
     unite_gemm_args a;
     uint32_t a_bytes, b_bytes;
+    int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
+    float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -85,10 +87,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
 
     // XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2) -> give each XCD a contiguous
     // range of tiles, N fastest, so the A row panel and the whole B operand stay L2-resident.
-    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nb = nbm * nbn;
-    const int bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
-    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nb = nbm * nbn, nbt = nb * p.splitk;
+    const int bid = blockIdx.x, xcd = bid & 7, qq = nbt >> 3, rr = nbt & 7;
+    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile = lin % nb, slice = lin / nb;      // neighbours on an XCD: different tiles of the SAME K slice
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+    const int k_begin = slice * p.k_chunk, k_end = min(g.K, k_begin + p.k_chunk);
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)p.b_bytes, 0x00020000);
@@ -99,9 +103,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + BK - 1) / BK;
-    stage_tile<TA>(rsA, smem, m0, 0, g.M, g.K, g.lda, wave, lane);
-    stage_tile<TB>(rsB, smem + TILE_BYTES, n0, 0, g.N, g.K, g.ldb, wave, lane);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    stage_tile<TA>(rsA, smem, m0, k_begin, g.M, k_end, g.lda, wave, lane);
+    stage_tile<TB>(rsB, smem + TILE_BYTES, n0, k_begin, g.N, k_end, g.ldb, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
         char* cur = smem + (t & 1) * STAGE_BYTES;
         char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
         if (t + 1 < nk) {
-            stage_tile<TA>(rsA, nxt, m0, (t + 1) * BK, g.M, g.K, g.lda, wave, lane);
-            stage_tile<TB>(rsB, nxt + TILE_BYTES, n0, (t + 1) * BK, g.N, g.K, g.ldb, wave, lane);
+            stage_tile<TA>(rsA, nxt, m0, k_begin + (t + 1) * BK, g.M, k_end, g.lda, wave, lane);
+            stage_tile<TB>(rsB, nxt + TILE_BYTES, n0, k_begin + (t + 1) * BK, g.N, k_end, g.ldb, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -154,6 +158,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
                 const f32x4 v1 = *(const f32x4*)(cs + lr * CS_LD + col + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
+                    float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
+                    *(f32x4*)sp = v0;
+                    *(f32x4*)(sp + 4) = v1;
+                    continue;
+                }
                 if (g.bias) {
                     const f32x4 b0 = *(const f32x4*)(g.bias + gn), b1 = *(const f32x4*)(g.bias + gn + 4);
 #pragma unroll
@@ -211,7 +221,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
     }
 }
 
+// out[m,n] (+)= sum_s slab[s][m,n]  -- fixed summation order, so weight gradients are bitwise reproducible
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splitk, int M, int N, float* __restrict__ out,
+                                                            int ldc, int accumulate) {
+    const size_t n4 = (size_t)N / 4, total = (size_t)M * n4, mn = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / n4, c = (i % n4) * 4;
+        f32x4 a = *(const f32x4*)(slab + m * N + c);
+        for (int s = 1; s < splitk; ++s) {
+            const f32x4 b = *(const f32x4*)(slab + (size_t)s * mn + m * N + c);
+            a = (f32x4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+        }
+        float* op = out + m * ldc + c;
+        if (accumulate) {
+            const f32x4 o = *(const f32x4*)op;
+            a = (f32x4){a[0] + o[0], a[1] + o[1], a[2] + o[2], a[3] + o[3]};
+        }
+        *(f32x4*)op = a;
+    }
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Split-K factor for short-and-wide problems (weight gradients: M x N = 768..3072 square-ish, K = tokens): choose the
+// slice count that minimises  waves(tiles * S over 512 resident workgroups) * (K/S + fixed cost), S <= 16.
+inline int choose_splitk(int tiles, int K, size_t slab_bytes_per_slice, size_t ws_bytes) {
+    if (tiles >= 384 || K < 1024) return 1;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 16; ++S) {
+        if ((size_t)S * slab_bytes_per_slice > ws_bytes && S > 1) break;
+        const int kc = ((K + S - 1) / S + BK - 1) / BK * BK;
+        if (S > 1 && kc < 256) break;
+        const double waves = (double)((tiles * S + 511) / 512);
+        const double cost = waves * (kc + 320.0) + (S > 1 ? 40.0 * S : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+    }
+    return best;
+}
 
 // launch-timing pool for bench.py's roofline leg (off by default; the only global state of this file)
 struct ProfState {
@@ -245,7 +292,22 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     p.a = g;
     p.a_bytes = (uint32_t)a_bytes;
     p.b_bytes = (uint32_t)b_bytes;
-    const int nb = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    p.splitk = 1;
+    p.k_chunk = (g.K + BK - 1) / BK * BK;
+    p.slab = nullptr;
+    const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
+    if (plain && g.workspace && aligned16(g.workspace)) {
+        const size_t per_slice = (size_t)g.M * g.N * sizeof(float);
+        const int S = choose_splitk(tiles, g.K, per_slice, (size_t)g.workspace_bytes);
+        if (S > 1) {
+            p.splitk = S;
+            p.k_chunk = ((g.K + S - 1) / S + BK - 1) / BK * BK;
+            p.splitk = (g.K + p.k_chunk - 1) / p.k_chunk;      // drop empty trailing slices
+            p.slab = (float*)g.workspace;
+        }
+    }
+    const int nb = tiles * p.splitk;
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
@@ -253,6 +315,12 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    if (p.splitk > 1) {
+        const size_t total4 = (size_t)g.M * g.N / 4;
+        const unsigned grid = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)p.slab, p.splitk, g.M, g.N, (float*)g.out, g.ldc,
+                           g.accumulate);
+    }
     if (prof) {
         (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
         g_prof.used++;

@@ -63,11 +63,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
                                                            int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
     float a = 0.f;
-    for (int i = 0; i < nparts; ++i) a += partial[(size_t)i * N + c];
-    out[c] = accumulate ? out[c] + a : a;
+    if (c < N)
+        for (int i = r; i < nparts; i += 4) a += partial[(size_t)i * N + c];
+    red[r][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (r == 0 && c < N) {
+        const int l = threadIdx.x;
+        a = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+        out[c] = accumulate ? out[c] + a : a;
+    }
 }
 
 // ------------------------------------------------------------------------------------ mask sampling
@@ -265,7 +272,7 @@ extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N,
                        (float*)workspace);
     UNITE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

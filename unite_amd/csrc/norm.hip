@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK_BWD = 32;    // 4 waves x 8 rows: dgamma/dbeta partial sums per workgroup
+constexpr int ROWS_PER_BLOCK_BWD = 16;    // 4 waves x 4 rows: dgamma/dbeta partial sums per workgroup
 
 template <int NV>
 __device__ __forceinline__ void load_row(const float* row, int D, int lane, f32x4 (&v)[NV]) {
@@ -162,18 +162,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// out_a[c] (+)= sum_b partial[b][0][c], out_b[c] (+)= sum_b partial[b][1][c]; fixed order -> deterministic
+// out_a[c] (+)= sum_b partial[b][0][c], out_b[c] (+)= sum_b partial[b][1][c]; fixed order -> deterministic.
+// One workgroup per 64 columns: thread (r, c) = (tid>>6, tid&63) sums partial rows r, r+4, ... (256-B coalesced row
+// segments), then the four row groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* __restrict__ out_a, float* __restrict__ out_b, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblocks; ++i) {
-        a += partial[((size_t)i * 2 + 0) * D + c];
-        b += partial[((size_t)i * 2 + 1) * D + c];
+    if (c < D) {
+        for (int i = r; i < nblocks; i += 4) {
+            a += partial[((size_t)i * 2 + 0) * D + c];
+            b += partial[((size_t)i * 2 + 1) * D + c];
+        }
     }
-    if (out_a) out_a[c] = accumulate ? out_a[c] + a : a;
-    if (out_b) out_b[c] = accumulate ? out_b[c] + b : b;
+    red[0][r][threadIdx.x & 63] = a;
+    red[1][r][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (r == 0 && c < D) {
+        const int l = threadIdx.x;
+        a = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        b = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+        if (out_a) out_a[c] = accumulate ? out_a[c] + a : a;
+        if (out_b) out_b[c] = accumulate ? out_b[c] + b : b;
+    }
 }
 
 // ------------------------------------------------------------------------------------ decoder tail
@@ -420,7 +432,7 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
                                       dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
                            dbeta, accumulate);
         UNITE_LAUNCH_CHECK();
     }
@@ -447,7 +459,7 @@ extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const 
                                       loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
                            dbeta, accumulate);
         UNITE_LAUNCH_CHECK();
     }

@@ -26,7 +26,7 @@ import torch.nn as nn
 from . import ops
 from .flat_params import FlatParams
 from .registry import register_model
-from .vit_runner import ViTRunner, BF16, F32
+from .vit_runner import ViTRunner, BF16, F32, SPLITK_WS_BYTES
 
 
 def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
@@ -293,13 +293,14 @@ class _StudentRuntime:
         dp = ctx["dp"]
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, C)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(r.Hd, 3 * D)))
+        gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
         # decoder heads: dgrad -> gradient of the normalised tap (bf16), wgrad/bias into the flat buffer
         for k in range(len(self.taps)):
             d, t = self.dec[k], self._tap[k]
             dy = ws.bufs[f"dec.dy{k}"]
             dxn = ws.get(f"dec.dxn{k}", (M, D), BF16)
             ops.gemm(dy, d["w"], dxn, trans_b=True)
-            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
             ops.colsum(dy, d["gb"], csws, accumulate=acc)
         if self.layer_done_hook is not None:
             self.layer_done_hook("clip_decoder")

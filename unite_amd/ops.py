@@ -42,7 +42,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
          aux_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 1,
          residual: Optional[torch.Tensor] = None, accumulate: bool = False,
-         out_bf16_copy: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out_bf16_copy: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views."""
     lib = _lib.load()
     _req(a, BF16, "a"); _req(b, BF16, "b")
@@ -72,6 +72,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
         raise TypeError("out must be bf16 or f32")
     g.out, g.ldc, g.out_f32, g.accumulate = _ptr(out), out.stride(0), int(out.dtype == F32), int(accumulate)
     g.out_bf16_copy, g.ld_copy = _ptr(out_bf16_copy), (out_bf16_copy.stride(0) if out_bf16_copy is not None else 0)
+    g.workspace, g.workspace_bytes = _ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
     _lib.check(lib.unite_gemm_bf16(C.byref(g), _stream()), "unite_gemm_bf16")
     return out
 

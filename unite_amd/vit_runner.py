@@ -21,6 +21,7 @@ from . import ops
 from .flat_params import FlatParams
 
 BF16, F32 = torch.bfloat16, torch.float32
+SPLITK_WS_BYTES = 16 * 3072 * 1024 * 4      # split-K slabs of the weight-gradient GEMMs: up to 16 slices of a 3072 x 1024 f32 tile
 
 
 class Workspace:
@@ -174,16 +175,17 @@ class ViTRunner:
         acc = fp.accumulate
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
+        gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
         for i in reversed(range(n_blocks)):
             w, s = self._blk[i], self.saved[i]
             # ---- MLP branch
             dz = ws.get("bw.dz", (M, Hd), BF16)
             ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
-            ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
             ops.colsum(dxb, w["g:mlp.fc2.bias"], csws, accumulate=acc)
             dh2 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
-            ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
             ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
             dx1 = ws.get("bw.dx1", (M, D), F32)
             dx1b = ws.get("bw.dx1b", (M, D), BF16)
@@ -193,14 +195,14 @@ class ViTRunner:
             # ---- attention branch
             do = ws.get("bw.do", (M, D), BF16)
             ops.gemm(dx1b, w["attn.proj.weight"], do, trans_b=True)
-            ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
             ops.colsum(dx1b, w["g:attn.proj.bias"], csws, accumulate=acc)
             dqkv = ws.get("bw.dqkv", (M, 3 * D), BF16)
             delta = ws.get("bw.delta", (B, H, N), F32)
             ops.attn_bwd(s["qkv"], s["o"], do, s["lse"], delta, dqkv, B, N, H, self.scale)
             dh1 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
-            ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc)
+            ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
             ops.colsum(dqkv[:, :D], w["g:attn.q_bias"], csws, accumulate=acc)
             ops.colsum(dqkv[:, 2 * D:], w["g:attn.v_bias"], csws, accumulate=acc)
             # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
@@ -224,5 +226,6 @@ class ViTRunner:
         cols = ws.bufs["pe.cols"]
         M = cols.shape[0]
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(self.Hd, 3 * D)))
-        ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate)
+        ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate,
+                 workspace=ws.bytes_("gemm.ws", SPLITK_WS_BYTES))
         ops.colsum(dxb, self._pe_gb, csws, accumulate=fp.accumulate)
