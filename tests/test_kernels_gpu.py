@@ -52,6 +52,22 @@ def test_gemm_exact_integers(ops, ta, tb, M, N, K):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 512), (4000, 3960, 200), (3848, 3592, 72)])
+def test_gemm_256_tile_exact_integers(ops, ta, tb, M, N, K):
+    """Large outputs (>= 200 tiles of 256 x 256) take the deep-pipelined 256 x 256 x 64 kernel: same bit-exact check,
+    including ragged edges in every dimension and K shorter than the 6-deep prefetch."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    b = torch.randint(-4, 5, (N, K), generator=g).float()
+    ref = (a @ b.t())                       # exact in f32: |sum| < 2^24
+    a_d = bf(a.t().contiguous() if ta else a).to(DEV)
+    b_d = bf(b.t().contiguous() if tb else b).to(DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a_d, b_d, out, trans_a=ta, trans_b=tb)
+    assert torch.equal(out.cpu(), ref)
+
+
 @pytest.mark.parametrize("M,N,K", [(768, 768, 10240), (3072, 768, 2560), (136, 264, 1100)])
 def test_gemm_splitk_weight_gradient(ops, M, N, K):
     """TN product with a workspace: split-K through f32 slabs, fixed summation order (bit-reproducible), exact on integers."""

@@ -15,6 +15,8 @@
 // The accumulators leave through LDS so that the epilogue (bias, GELU / QuickGELU / GELU', stochastic-depth
 // row scale, residual add, bf16 + f32 outputs) reads and writes 16 B (bf16) / 32 B (f32) per lane.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 
@@ -74,6 +76,71 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
         const s16x4 hi = lds_read_tr16(lds_tile + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (p & 1));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// Epilogue for 8 consecutive output columns of one row (f32 accumulators v0|v1): see unite_hip.h for the order of operations.
+__device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int gm, int gn, f32x4 v0, f32x4 v1) {
+    const unite_gemm_args& g = p.a;
+    if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
+        float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
+        *(f32x4*)sp = v0;
+        *(f32x4*)(sp + 4) = v1;
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+    if (g.bias) {
+        const f32x4 b0 = *(const f32x4*)(g.bias + gn), b1 = *(const f32x4*)(g.bias + gn + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (g.act == UNITE_ACT_GELU) {
+        if (g.aux_out) {
+            u32x4 z = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            *(u32x4*)((uint16_t*)g.aux_out + (size_t)gm * g.ld_aux_out + gn) = z;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    } else if (g.act == UNITE_ACT_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
+    } else if (g.act == UNITE_ACT_DGELU) {
+        const u32x4 z = *(const u32x4*)((const uint16_t*)g.aux_in + (size_t)gm * g.ld_aux_in + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= gelu_erf_grad(__uint_as_float(z[e] << 16));
+            v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(z[e] & 0xFFFF0000u));
+        }
+    }
+    if (g.row_scale) {
+        const float sc = g.row_scale[gm / g.rows_per_scale];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= sc;
+    }
+    if (g.residual) {
+        const float* rp = g.residual + (size_t)gm * g.ldr + gn;
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+    }
+    if (g.out_f32) {
+        float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
+        if (g.accumulate) {
+            const f32x4 o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+        }
+        *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+        u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+    }
+    if (g.out_bf16_copy) {
+        u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
     }
 }
 
@@ -152,72 +219,215 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
             const int lr = pass * 16 + (tid >> 4);
             const int col = (tid & 15) * 8;
             const int gm = m0 + half * 64 + lr, gn = n0 + col;
-            if (gm < g.M && gn < g.N) {
-                float v[8];
-                const f32x4 v0 = *(const f32x4*)(cs + lr * CS_LD + col);
-                const f32x4 v1 = *(const f32x4*)(cs + lr * CS_LD + col + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
-                    float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
-                    *(f32x4*)sp = v0;
-                    *(f32x4*)(sp + 4) = v1;
-                    continue;
-                }
-                if (g.bias) {
-                    const f32x4 b0 = *(const f32x4*)(g.bias + gn), b1 = *(const f32x4*)(g.bias + gn + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (g.act == UNITE_ACT_GELU) {
-                    if (g.aux_out) {
-                        u32x4 z = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                        *(u32x4*)((uint16_t*)g.aux_out + (size_t)gm * g.ld_aux_out + gn) = z;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-                } else if (g.act == UNITE_ACT_QUICKGELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
-                } else if (g.act == UNITE_ACT_DGELU) {
-                    const u32x4 z = *(const u32x4*)((const uint16_t*)g.aux_in + (size_t)gm * g.ld_aux_in + gn);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] *= gelu_erf_grad(__uint_as_float(z[e] << 16));
-                        v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(z[e] & 0xFFFF0000u));
-                    }
-                }
-                if (g.row_scale) {
-                    const float s = g.row_scale[gm / g.rows_per_scale];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= s;
-                }
-                if (g.residual) {
-                    const float* rp = g.residual + (size_t)gm * g.ldr + gn;
-                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-                }
-                if (g.out_f32) {
-                    float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
-                    if (g.accumulate) {
-                        const f32x4 o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
-                    }
-                    *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
-                    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                    *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
-                }
-                if (g.out_bf16_copy) {
-                    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                    *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
-                }
-            }
+            if (gm < g.M && gn < g.N)
+                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CS_LD + col), *(const f32x4*)(cs + lr * CS_LD + col + 4));
         }
         __syncthreads();
+    }
+}
+
+// =====================================================================================================================
+// Deep-pipelined kernel.  Tile = (2 HALF) x (2 HALF) x 64 with HALF = 128 (8 waves, 1 workgroup / CU, 128 KiB LDS) or
+// HALF = 64 (4 waves, 2 workgroups / CU, 64 KiB LDS each).  The LDS holds two K-tiles of four half-tiles (A rows 0..HALF-1
+// / HALF..2HALF-1, B cols likewise).  Each K-tile is computed in four phases, one quadrant of the wave's output each;
+// wave (wm, wn) owns rows {h HALF + wm HALF/2 ..} and columns {nh HALF + wn 32 ..} of BOTH halves, so quadrant (h, nh)
+// reads only half-tiles A_h and B_nh.  With the quadrant order (0,0) (0,1) (1,1) (1,0) the half-tiles of K-tile t are first
+// needed at phases 1 (A0, B0), 2 (B1), 3 (A1) and are dead one phase later, which lets the LDS-DMA stream run far ahead
+// through only two K-tiles of LDS:
+//   at global phase g the wave issues half-tile load q = g + 6   (sequence A0,B0,B1,A1 per K-tile, 2 DMAs per wave),
+//   phases 1-3 start with  s_waitcnt vmcnt(8); s_barrier  (4 half-tiles stay in flight across the barrier),
+// and the queue is never drained inside the loop.  The B0 fragments stay in registers for phase 4.  Loads past the last
+// K-tile still issue (their k is out of range: they only zero-fill a dead slot) so that the vmcnt arithmetic is uniform.
+// =====================================================================================================================
+__device__ __forceinline__ int swz128t(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }   // 32-B chunk swizzle of [k][64] images
+
+// one 1-KiB LDS-DMA piece `it` of a half-tile image (HALF rows/cols x 64 k)
+template <bool TR, int HALF>
+__device__ __forceinline__ void stage_piece(__amdgpu_buffer_rsrc_t rs, char* slot, int it, int r0, int k0, int R, int K, int ld, int lane) {
+    uint32_t voff;
+    if (!TR) {                                   // image [HALF][64 k], 128-B rows, 16-B chunk c at c ^ (row & 7)
+        const int r = it * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ (r & 7);
+        const int gr = r0 + r, gk = k0 + lc * 8;
+        voff = (gr < R && gk < K) ? (uint32_t)(gr * ld + gk) * 2u : OOB_OFFSET;
+    } else if (HALF == 128) {                    // image [64 k][128], 256-B rows, swz256
+        const int kr = it * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ swz256(kr);
+        const int gk = k0 + kr, gr = r0 + lc * 8;
+        voff = (gk < K && gr < R) ? (uint32_t)(gk * ld + gr) * 2u : OOB_OFFSET;
+    } else {                                     // image [64 k][64], 128-B rows, 32-B chunk c at c ^ swz128t(k)
+        const int kr = it * 8 + (lane >> 3), pc = lane & 7;
+        const int lc = (((pc >> 1) ^ swz128t(kr)) << 1) | (pc & 1);
+        const int gk = k0 + kr, gr = r0 + lc * 8;
+        voff = (gk < K && gr < R) ? (uint32_t)(gk * ld + gr) * 2u : OOB_OFFSET;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(slot + it * 1024), 16, voff, 0, 0, 0);
+}
+
+template <bool TR, int HALF>
+__device__ __forceinline__ bf16x8 load_frag_h(const char* slot, int row0, int ks, int lane) {
+    if (!TR || HALF == 128) return load_frag<TR>(slot, row0, ks, lane);
+    const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int c32 = row0 >> 4;
+    const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
+    const s16x4 lo = lds_read_tr16(slot + 128 * k_lo + ((c32 ^ swz128t(k_lo)) << 5) + 8 * pp);
+    const s16x4 hi = lds_read_tr16(slot + 128 * k_hi + ((c32 ^ swz128t(k_hi)) << 5) + 8 * pp);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int HALF, bool TA, bool TB>
+__global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32, CLD = HALF + 4;
+    const unite_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nbn = (g.N + TILE - 1) / TILE, nbm = (g.M + TILE - 1) / TILE, nb = nbm * nbn, nbt = nb * p.splitk;
+    const int bid = blockIdx.x, xcd = bid & 7, qq = nbt >> 3, rr = nbt & 7;
+    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile = lin % nb, slice = lin / nb;
+    const int m0 = (tile / nbn) * TILE, n0 = (tile % nbn) * TILE;
+    const int k_begin = slice * p.k_chunk, k_end = min(g.K, k_begin + p.k_chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)p.b_bytes, 0x00020000);
+
+    // half-tile load number q: K-tile u = q >> 2, kind = q & 3 (0: A0, 1: B0, 2: B1, 3: A1); slots of set (u & 1): A0 A1 B0 B1
+    auto issue = [&](int q) {
+        const int u = q >> 2, kind = q & 3;
+        char* set = smem + (u & 1) * (4 * SLOT);
+        const int k0 = k_begin + u * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int it = wave * 2 + i;
+            if (kind == 0) stage_piece<TA, HALF>(rsA, set, it, m0, k0, g.M, k_end, g.lda, lane);
+            else if (kind == 1) stage_piece<TB, HALF>(rsB, set + 2 * SLOT, it, n0, k0, g.N, k_end, g.ldb, lane);
+            else if (kind == 2) stage_piece<TB, HALF>(rsB, set + 3 * SLOT, it, n0 + HALF, k0, g.N, k_end, g.ldb, lane);
+            else stage_piece<TA, HALF>(rsA, set + SLOT, it, m0 + HALF, k0, g.M, k_end, g.lda, lane);
+        }
+    };
+
+    f32x4 acc[2][MT][2][2];       // [A half][m-tile][B half][n-tile]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][i][nh][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue(q);
+
+    const int arow = wm * (HALF / 2), bcol = wn * 32;
+    for (int t = 0; t < nk; ++t) {
+        char* set = smem + (t & 1) * (4 * SLOT);
+        const char* A0 = set;
+        const char* A1 = set + SLOT;
+        const char* B0 = set + 2 * SLOT;
+        const char* B1 = set + 3 * SLOT;
+        const int gph = 4 * t;
+        bf16x8 af[MT][2], b0f[2][2], b1f[2][2];
+
+        // ---- phase 1: quadrant (0,0); A0 and B0 of this K-tile have landed once at most 8 DMAs are outstanding
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, HALF>(A0, arow + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b0f[j][ks] = load_frag_h<TB, HALF>(B0, bcol + j * 16, ks, lane);
+        issue(gph + 6);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma16(af[i][ks], b0f[j][ks], acc[0][i][0][j]);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- phase 2: quadrant (0,1); needs B1
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b1f[j][ks] = load_frag_h<TB, HALF>(B1, bcol + j * 16, ks, lane);
+        issue(gph + 7);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma16(af[i][ks], b1f[j][ks], acc[0][i][1][j]);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- phase 3: quadrant (1,1); needs A1
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, HALF>(A1, arow + i * 16, ks, lane);
+        issue(gph + 8);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma16(af[i][ks], b1f[j][ks], acc[1][i][1][j]);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- phase 4: quadrant (1,0); operands already in registers
+        issue(gph + 9);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma16(af[i][ks], b0f[j][ks], acc[1][i][0][j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-fill DMAs must not land in the epilogue image
+    __syncthreads();
+
+    // ---- epilogue: one HALF x HALF output quadrant (A half h, B half nh) at a time through LDS -> 16-B coalesced stores
+    float* cs = (float*)smem;
+    const int G = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(arow + i * 16 + 4 * G + r) * CLD + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
+            __syncthreads();
+#pragma unroll 1
+            for (int pass = 0; pass < HALF / 32; ++pass) {
+                const int lr = pass * 32 + tid / (HALF / 8);
+                const int col = (tid % (HALF / 8)) * 8;
+                const int gm = m0 + h * HALF + lr, gn = n0 + nh * HALF + col;
+                if (gm < g.M && gn < g.N)
+                    epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CLD + col), *(const f32x4*)(cs + lr * CLD + col + 4));
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -292,7 +502,18 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     p.a = g;
     p.a_bytes = (uint32_t)a_bytes;
     p.b_bytes = (uint32_t)b_bytes;
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    // kernel choice (UNITE_GEMM_KERNEL = simple | deep128 | deep256 overrides): estimated time = rounds x (K-tiles x c + e)
+    // with (c, e) per kernel measured on MI355X (rounds = tiles over resident workgroups); see DESIGN.md.
+    static const char* force = getenv("UNITE_GEMM_KERNEL");
+    const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    int kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2
+    if (force) kind = !strcmp(force, "simple") ? 0 : !strcmp(force, "deep256") ? 2 : 1;
+    else {
+        const double kt = (g.K + BK - 1) / BK;
+        const double c128 = ((t128 + 511) / 512) * (kt * 1.0 + 3.0), c256 = ((t256 + 255) / 256) * (kt * 1.51 * 2 + 9.8 * 2) / 2.0;
+        kind = (t256 >= 128 && c256 < c128) ? 2 : 1;
+    }
+    const int tiles = kind == 2 ? t256 : t128;
     p.splitk = 1;
     p.k_chunk = (g.K + BK - 1) / BK * BK;
     p.slab = nullptr;
@@ -311,7 +532,27 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
-    if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    if (kind == 2) {
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            const void* ks[4] = {(const void*)gemm_deep_kernel<128, false, false>, (const void*)gemm_deep_kernel<128, false, true>,
+                                 (const void*)gemm_deep_kernel<128, true, false>, (const void*)gemm_deep_kernel<128, true, true>};
+            for (const void* k : ks) {
+                hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
+                if (e != hipSuccess) return (int)e;
+            }
+            lds_ok = true;
+        }
+        if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, true, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        else hipLaunchKernelGGL((gemm_deep_kernel<128, true, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+    } else if (kind == 1) {
+        if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+    } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
