@@ -17,6 +17,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -33,6 +34,7 @@ struct Params {
     uint32_t a_bytes, b_bytes;
     int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
     float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
+    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue stores; 2: no MFMA)
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -80,7 +82,9 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 }
 
 // Epilogue for 8 consecutive output columns of one row (f32 accumulators v0|v1): see unite_hip.h for the order of operations.
-__device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int gm, int gn, f32x4 v0, f32x4 v1) {
+// The bias chunk (b0|b1) is loaded by the caller ONCE per tile, ahead of the stores: vmcnt retires in issue order, so a
+// load issued between the stores of two passes could only be waited for together with every store before it.
+__device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int gm, int gn, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
     const unite_gemm_args& g = p.a;
     if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
         float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
@@ -91,11 +95,8 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
     float v[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-    if (g.bias) {
-        const f32x4 b0 = *(const f32x4*)(g.bias + gn), b1 = *(const f32x4*)(g.bias + gn + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-    }
+    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
     if (g.act == UNITE_ACT_GELU) {
         if (g.aux_out) {
             u32x4 z = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
@@ -125,6 +126,10 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
     }
+    if (p.debug_skip == 2) {      // timing experiment: everything but the stores
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        return;
+    }
     if (g.out_f32) {
         float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
         if (g.accumulate) {
@@ -141,6 +146,14 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
     if (g.out_bf16_copy) {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
+    }
+}
+
+__device__ __forceinline__ void load_bias8(const unite_gemm_args& g, int gn, f32x4& b0, f32x4& b1) {
+    b0 = b1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (g.bias && gn < g.N) {
+        b0 = *(const f32x4*)(g.bias + gn);
+        b1 = *(const f32x4*)(g.bias + gn + 4);
     }
 }
 
@@ -169,6 +182,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bias0, bias1;
+    load_bias8(g, n0 + (tid & 15) * 8, bias0, bias1);
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
     stage_tile<TA>(rsA, smem, m0, k_begin, g.M, k_end, g.lda, wave, lane);
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
             const int col = (tid & 15) * 8;
             const int gm = m0 + half * 64 + lr, gn = n0 + col;
             if (gm < g.M && gn < g.N)
-                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CS_LD + col), *(const f32x4*)(cs + lr * CS_LD + col + 4));
+                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CS_LD + col), *(const f32x4*)(cs + lr * CS_LD + col + 4), bias0, bias1);
         }
         __syncthreads();
     }
@@ -279,7 +294,7 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* slot, int row0, int ks
 template <int HALF, bool TA, bool TB>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32, CLD = HALF + 4;
+    constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32;
     const unite_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,6 +338,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 
 #pragma unroll
     for (int q = 0; q < 6; ++q) issue(q);
+    f32x4 bias0, bias1;
+    load_bias8(g, n0 + (tid % (TILE / 8)) * 8, bias0, bias1);
 
     const int arow = wm * (HALF / 2), bcol = wn * 32;
     for (int t = 0; t < nk; ++t) {
@@ -402,32 +419,44 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-fill DMAs must not land in the epilogue image
     __syncthreads();
+    if (p.debug_skip == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[h][i][nh][j]));
+        return;
+    }
 
-    // ---- epilogue: one HALF x HALF output quadrant (A half h, B half nh) at a time through LDS -> 16-B coalesced stores
+    // ---- epilogue: HALF rows x TILE columns at a time through an unpadded f32 image in the (now idle) ring: two passes,
+    // two barriers each, TILE/32 independent 8-column chunks per thread -> wide (16 B / 32 B per lane) coalesced stores.
     float* cs = (float*)smem;
     const int G = lane >> 4, c16 = lane & 15;
+    constexpr int CPR = TILE / 8;                     // 8-column chunks per row
+    const int ccol = (tid % CPR) * 8;                 // this thread's column chunk is the same in every pass
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        cs[(arow + i * 16 + 4 * G + r) * CLD + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
-            __syncthreads();
-#pragma unroll 1
-            for (int pass = 0; pass < HALF / 32; ++pass) {
-                const int lr = pass * 32 + tid / (HALF / 8);
-                const int col = (tid % (HALF / 8)) * 8;
-                const int gm = m0 + h * HALF + lr, gn = n0 + nh * HALF + col;
-                if (gm < g.M && gn < g.N)
-                    epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CLD + col), *(const f32x4*)(cs + lr * CLD + col + 4));
-            }
-            __syncthreads();
+                        cs[(arow + i * 16 + 4 * G + r) * TILE + nh * HALF + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
+        __syncthreads();
+#pragma unroll 2
+        for (int e = 0; e < TILE / 32; ++e) {
+            const int lr = (tid + e * 4 * HALF) / CPR;
+            const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
+            if (gm < g.M && gn < g.N)
+                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * TILE + ccol), *(const f32x4*)(cs + lr * TILE + ccol + 4), bias0, bias1);
         }
+        __syncthreads();
     }
 }
 
@@ -509,14 +538,19 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     int kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2
     if (force) kind = !strcmp(force, "simple") ? 0 : !strcmp(force, "deep256") ? 2 : 1;
     else {
-        const double kt = (g.K + BK - 1) / BK;
-        const double c128 = ((t128 + 511) / 512) * (kt * 1.0 + 3.0), c256 = ((t256 + 255) / 256) * (kt * 1.51 * 2 + 9.8 * 2) / 2.0;
-        kind = (t256 >= 128 && c256 < c128) ? 2 : 1;
+        // time ~ rounds x (K-tiles x c + e), (c, e) in us fitted on MI355X: 128^2 tile (2 workgroups / CU): c 1.006, e 4.4;
+        // 256^2 tile (1 / CU): c 1.51, e 9.8.  The wide tile wins when N is large enough to keep its last round full.
+        const double kt = (double)((g.K + BK - 1) / BK);
+        const double c128 = (double)((t128 + 511) / 512) * (kt * 1.006 + 4.4);
+        const double c256 = (double)((t256 + 255) / 256) * (kt * 1.51 + 9.8);
+        kind = c256 < c128 ? 2 : 1;
     }
     const int tiles = kind == 2 ? t256 : t128;
     p.splitk = 1;
     p.k_chunk = (g.K + BK - 1) / BK * BK;
     p.slab = nullptr;
+    static const int dbg = getenv("UNITE_GEMM_DEBUG_SKIP") ? atoi(getenv("UNITE_GEMM_DEBUG_SKIP")) : 0;
+    p.debug_skip = dbg;
     const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
     if (plain && g.workspace && aligned16(g.workspace)) {
         const size_t per_slice = (size_t)g.M * g.N * sizeof(float);
