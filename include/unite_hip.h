@@ -97,21 +97,23 @@ int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index,
 /* Backward of y = LN(x)*gamma+beta.  dy is bf16 (dy_f32 == 0) or f32 [M,D].
  *   dx_out[i,:] = (dx_residual ? dx_residual[i,:] : 0) + dLN/dx
  *   dx_bf16[i,:] = bf16(row_scale[i / rows_per_scale] * dx_out[i,:])      (optional)
- *   dgamma/dbeta (f32 [D]) are OVERWRITTEN (accumulate == 0) or added to; partial sums go
- *   through `workspace` (>= unite_layernorm_bwd_workspace(M, D) bytes) -> deterministic. */
+ *   dgamma/dbeta (f32 [D]) are OVERWRITTEN or added to (accumulate bit 0), dxsum likewise (accumulate bit 1);
+ *   partial sums go through `workspace` (>= unite_layernorm_bwd_workspace(M, D) bytes) -> deterministic. */
 size_t unite_layernorm_bwd_workspace(int32_t M, int32_t D);
 int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* x, int32_t ldx,
                         const float* mean, const float* rstd, const float* gamma,
                         const float* dx_residual, float* dx_out,
                         void* dx_bf16, const float* row_scale, int32_t rows_per_scale,
-                        float* dgamma, float* dbeta, int32_t accumulate,
+                        float* dgamma, float* dbeta,
+                        float* dxsum,      /* optional f32 [D]: column sums of dx_bf16 = bias gradient of the Linear that consumes it */
+                        int32_t accumulate,
                         void* workspace, int32_t M, int32_t D, void* stream);
 
-/* Column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m x[m,n].
- * workspace >= unite_colsum_workspace(M, N) bytes. */
+/* Column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m x[m,n]; columns in [zero_lo, zero_hi) are written
+ * as 0 instead (the k third of the packed (q,0,v) attention bias).  workspace >= unite_colsum_workspace(M, N) bytes. */
 size_t unite_colsum_workspace(int32_t M, int32_t N);
 int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
-                      void* workspace, void* stream);
+                      int32_t zero_lo, int32_t zero_hi, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused multi-head self-attention on a packed qkv matrix [B*N, 3*H*64] (bf16, row = token,
@@ -187,7 +189,9 @@ int unite_decoder_tail_fwd(const float* y, const float* gamma, const float* beta
                            const float* tgt, float* out, float* loss_sum, int32_t M, int32_t C, void* stream);
 int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps,
                            const float* tgt, float loss_scale, const float* loss_scale_dev, const float* dout,
-                           void* dy_bf16, float* dgamma, float* dbeta, int32_t accumulate,
+                           void* dy_bf16, float* dgamma, float* dbeta,
+                           float* dysum,   /* optional f32 [C]: column sums of dy_bf16 = bias gradient of the decoder head */
+                           int32_t accumulate,
                            void* workspace, int32_t M, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------

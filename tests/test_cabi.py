@@ -38,7 +38,7 @@ def test_ctypes_table_matches_header():
 
 def test_workspace_queries_run_without_gpu():
     from unite_amd import ops
-    assert ops.layernorm_bwd_workspace(10240, 768) == (10240 // 16) * 2 * 768 * 4
+    assert ops.layernorm_bwd_workspace(10240, 768) == (10240 // 16) * 3 * 768 * 4
     assert ops.colsum_workspace(1000, 776) > 0
     assert ops.grad_norm_workspace(88_005_888) > 0
 

@@ -174,6 +174,15 @@ def test_layernorm_fwd_bwd(ops, M, D):
     dres = rnd(M, D, seed=6)
     dx = torch.empty(M, D, device=DEV); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
     dgam = torch.empty(D, device=DEV); dbet = torch.empty(D, device=DEV)
+    dsum = torch.empty(D, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.to(DEV), dx_residual=dres.to(DEV), dx_out=dx, dx_bf16=dxb,
+                      dgamma=dgam, dbeta=dbet, dxsum=dsum, workspace=ws)
+    torch.testing.assert_close(dsum.cpu(), dxb.float().sum(0).cpu(), atol=1e-3, rtol=1e-5)      # bias gradient of the consumer
+    # accumulate bits: bit 0 adds gamma/beta, bit 1 leaves the column sums overwritten
+    ops.layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.to(DEV), dx_residual=dres.to(DEV), dx_out=dx, dx_bf16=dxb,
+                      dgamma=dgam, dbeta=dbet, dxsum=dsum, accumulate=1, workspace=ws)
+    torch.testing.assert_close(dgam.cpu(), 2 * gg.grad, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(dsum.cpu(), dxb.float().sum(0).cpu(), atol=1e-3, rtol=1e-5)
     ops.layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.to(DEV), dx_residual=dres.to(DEV), dx_out=dx, dx_bf16=dxb,
                       dgamma=dgam, dbeta=dbet, workspace=ws)
     torch.testing.assert_close(dx.cpu(), xg.grad + dres, atol=1e-4, rtol=1e-4)
@@ -192,6 +201,10 @@ def test_colsum(ops):
     wide = bf(rnd(M, 3 * 256, seed=2)).to(DEV)
     ops.colsum(wide[:, 512:], out[:256], ws, accumulate=False)
     torch.testing.assert_close(out[:256].cpu(), wide[:, 512:].float().sum(0).cpu(), atol=1e-3, rtol=1e-4)
+    ops.colsum(wide, out[:768], ws, zero_range=(256, 512))          # (q, 0, v) bias gradient in one launch
+    ref = wide.float().sum(0).cpu()
+    ref[256:512] = 0
+    torch.testing.assert_close(out[:768].cpu(), ref, atol=1e-3, rtol=1e-4)
 
 
 # ------------------------------------------------------------------------------------ attention
@@ -352,7 +365,9 @@ def test_decoder_tail(ops, M, Cd):
     torch.testing.assert_close(ls.cpu()[0], loss_sum.detach(), atol=1e-3, rtol=1e-5)
     ws = torch.empty(ops.layernorm_bwd_workspace(M, Cd), dtype=torch.uint8, device=DEV)
     dy = torch.empty(M, Cd, dtype=torch.bfloat16, device=DEV); dg = torch.empty(Cd, device=DEV); db = torch.empty(Cd, device=DEV)
-    ops.decoder_tail_bwd(yd, gd, bd, 1e-6, td, scale, None, dy, dg, db, ws)
+    dys = torch.empty(Cd, device=DEV)
+    ops.decoder_tail_bwd(yd, gd, bd, 1e-6, td, scale, None, dy, dg, db, ws, dysum=dys)
+    torch.testing.assert_close(dys.cpu(), dy.float().sum(0).cpu(), atol=1e-5, rtol=1e-4)
     assert (dy.float().cpu() - yg.grad).abs().max() <= 1e-2 * yg.grad.abs().max() + 1e-8
     torch.testing.assert_close(dg.cpu(), gg.grad, atol=1e-5, rtol=1e-3)
     torch.testing.assert_close(db.cpu(), bg.grad, atol=1e-5, rtol=1e-3)

@@ -49,9 +49,9 @@ SIGNATURES = {
     "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
-    "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_colsum_workspace": (c_sz, [c_i, c_i]),
-    "unite_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
+    "unite_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "unite_attn_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "unite_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "unite_attn_cls_probs": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
@@ -63,7 +63,7 @@ SIGNATURES = {
     "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_mask_to_tokens": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_decoder_tail_fwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
-    "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_adamw_flat": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
     "unite_cast_f32_bf16": (c_i, [c_p, c_p, c_i64, c_p]),
     "unite_grad_norm_workspace": (c_sz, [c_i64]),

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
     }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
-                                                           int accumulate) {
+                                                           int accumulate, int zero_lo, int zero_hi) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
     float a = 0.f;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (r == 0 && c < N) {
         const int l = threadIdx.x;
         a = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+        if (c >= zero_lo && c < zero_hi) a = 0.f;
         out[c] = accumulate ? out[c] + a : a;
     }
 }
@@ -264,15 +265,15 @@ extern "C" size_t unite_colsum_workspace(int32_t M, int32_t N) {
     return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
 }
 
-extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* workspace,
-                                 void* stream) {
+extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, int32_t zero_lo,
+                                 int32_t zero_hi, void* workspace, void* stream) {
     if (!x || !out || !workspace || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UNITE_EINVAL;
     const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N,
                        (float*)workspace);
     UNITE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate, zero_lo, zero_hi);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

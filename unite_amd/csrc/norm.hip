@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             float* __restrict__ dx_out, void* __restrict__ dx_bf16,
                                                             const float* __restrict__ row_scale, int rows_per_scale,
                                                             float* __restrict__ partial, int M, int D) {
-    __shared__ float red[4][2][NV * 256];
+    __shared__ float red[4][3][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 gam[NV], dg[NV], db[NV];
+    f32x4 gam[NV], dg[NV], db[NV], ds[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         gam[i] = (c < D) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dg[i] = db[i] = ds[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
         const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
@@ -141,50 +141,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                     for (int e = 0; e < 4; ++e) o[e] += a[e];
                 }
                 if (dx_out) *(f32x4*)(dx_out + (size_t)row * D + c) = o;
-                if (dx_bf16)
-                    *(u32x2*)((uint16_t*)dx_bf16 + (size_t)row * D + c) =
-                        (u32x2){pack_bf16x2(sc * o[0], sc * o[1]), pack_bf16x2(sc * o[2], sc * o[3])};
+                if (dx_bf16) {
+                    const u32x2 w = (u32x2){pack_bf16x2(sc * o[0], sc * o[1]), pack_bf16x2(sc * o[2], sc * o[3])};
+                    *(u32x2*)((uint16_t*)dx_bf16 + (size_t)row * D + c) = w;
+                    // column sums of exactly what the consuming GEMMs read (its bias gradient)
+                    ds[i][0] += __uint_as_float(w[0] << 16);
+                    ds[i][1] += __uint_as_float(w[0] & 0xFFFF0000u);
+                    ds[i][2] += __uint_as_float(w[1] << 16);
+                    ds[i][3] += __uint_as_float(w[1] & 0xFFFF0000u);
+                }
             }
         }
     }
-    // workgroup partial sums -> partial[block][2][D]
+    // workgroup partial sums -> partial[block][3][D]
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[wave][0][(i * 64 + lane) * 4 + e] = dg[i][e];
             red[wave][1][(i * 64 + lane) * 4 + e] = db[i][e];
+            red[wave][2][(i * 64 + lane) * 4 + e] = ds[i][e];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            partial[((size_t)blockIdx.x * 3 + k) * D + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
     }
 }
 
-// out_a[c] (+)= sum_b partial[b][0][c], out_b[c] (+)= sum_b partial[b][1][c]; fixed order -> deterministic.
+// out_k[c] (+)= sum_b partial[b][k][c], k = 0..2; fixed order -> deterministic.
 // One workgroup per 64 columns: thread (r, c) = (tid>>6, tid&63) sums partial rows r, r+4, ... (256-B coalesced row
 // segments), then the four row groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                                              float* __restrict__ out_a, float* __restrict__ out_b, int accumulate) {
-    __shared__ float red[2][4][64];
+                                                              float* __restrict__ out_a, float* __restrict__ out_b, float* __restrict__ out_c,
+                                                              int accumulate) {
+    __shared__ float red[3][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, d = 0.f;
     if (c < D) {
         for (int i = r; i < nblocks; i += 4) {
-            a += partial[((size_t)i * 2 + 0) * D + c];
-            b += partial[((size_t)i * 2 + 1) * D + c];
+            a += partial[((size_t)i * 3 + 0) * D + c];
+            b += partial[((size_t)i * 3 + 1) * D + c];
+            d += partial[((size_t)i * 3 + 2) * D + c];
         }
     }
     red[0][r][threadIdx.x & 63] = a;
     red[1][r][threadIdx.x & 63] = b;
+    red[2][r][threadIdx.x & 63] = d;
     __syncthreads();
     if (r == 0 && c < D) {
         const int l = threadIdx.x;
         a = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
         b = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-        if (out_a) out_a[c] = accumulate ? out_a[c] + a : a;
-        if (out_b) out_b[c] = accumulate ? out_b[c] + b : b;
+        d = red[2][0][l] + red[2][1][l] + red[2][2][l] + red[2][3][l];
+        // accumulate: bit 0 -> out_a/out_b (gamma/beta gradients), bit 1 -> out_c (bias column sums)
+        if (out_a) out_a[c] = (accumulate & 1) ? out_a[c] + a : a;
+        if (out_b) out_b[c] = (accumulate & 1) ? out_b[c] + b : b;
+        if (out_c) out_c[c] = (accumulate & 2) ? out_c[c] + d : d;
     }
 }
 
@@ -245,16 +259,16 @@ __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __re
                                                                float loss_scale, const float* __restrict__ loss_scale_dev,
                                                                const float* __restrict__ dout, void* __restrict__ dy_bf16,
                                                                float* __restrict__ partial, int M, int C) {
-    __shared__ float red[4][2][NV * 256];
+    __shared__ float red[4][3][NV * 256];
     if (loss_scale_dev) loss_scale *= *loss_scale_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 gam[NV], bet[NV], dg[NV], db[NV];
+    f32x4 gam[NV], bet[NV], dg[NV], db[NV], ds[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         gam[i] = (c < C) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         bet[i] = (c < C) ? *(const f32x4*)(beta + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        dg[i] = db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dg[i] = db[i] = ds[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
         const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
@@ -312,7 +326,12 @@ __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __re
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (u[i][e] - s1 - v[i][e] * s2);
-                *(u32x2*)((uint16_t*)dy_bf16 + (size_t)row * C + c) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                const u32x2 w = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                *(u32x2*)((uint16_t*)dy_bf16 + (size_t)row * C + c) = w;
+                ds[i][0] += __uint_as_float(w[0] << 16);
+                ds[i][1] += __uint_as_float(w[0] & 0xFFFF0000u);
+                ds[i][2] += __uint_as_float(w[1] << 16);
+                ds[i][3] += __uint_as_float(w[1] & 0xFFFF0000u);
             }
         }
     }
@@ -322,11 +341,13 @@ __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __re
         for (int e = 0; e < 4; ++e) {
             red[wave][0][(i * 64 + lane) * 4 + e] = dg[i][e];
             red[wave][1][(i * 64 + lane) * 4 + e] = db[i][e];
+            red[wave][2][(i * 64 + lane) * 4 + e] = ds[i][e];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            partial[((size_t)blockIdx.x * 3 + k) * C + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
     }
 }
 
@@ -417,13 +438,13 @@ extern "C" int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* r
 
 extern "C" size_t unite_layernorm_bwd_workspace(int32_t M, int32_t D) {
     const size_t nb = (size_t)(M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
-    return nb * 2 * (size_t)D * sizeof(float);
+    return nb * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* x, int32_t ldx, const float* mean, const float* rstd,
                                    const float* gamma, const float* dx_residual, float* dx_out, void* dx_bf16,
-                                   const float* row_scale, int32_t rows_per_scale, float* dgamma, float* dbeta, int32_t accumulate,
-                                   void* workspace, int32_t M, int32_t D, void* stream) {
+                                   const float* row_scale, int32_t rows_per_scale, float* dgamma, float* dbeta, float* dxsum,
+                                   int32_t accumulate, void* workspace, int32_t M, int32_t D, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !workspace || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
     if (row_scale && rows_per_scale <= 0) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -431,9 +452,10 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma,
                                       dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
     UNITE_LAUNCH_CHECK();
-    if (dgamma || dbeta) {
+    if (dxsum && !dx_bf16) return UNITE_EINVAL;
+    if (dgamma || dbeta || dxsum) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
-                           dbeta, accumulate);
+                           dbeta, dxsum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
     return UNITE_OK;
@@ -451,16 +473,16 @@ extern "C" int unite_decoder_tail_fwd(const float* y, const float* gamma, const 
 
 extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta, float eps, const float* tgt,
                                       float loss_scale, const float* loss_scale_dev, const float* dout, void* dy_bf16, float* dgamma, float* dbeta,
-                                      int32_t accumulate, void* workspace, int32_t M, int32_t C, void* stream) {
+                                      float* dysum, int32_t accumulate, void* workspace, int32_t M, int32_t C, void* stream) {
     if (!y || !gamma || !beta || !dy_bf16 || !workspace || (!tgt && !dout) || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
     DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, y, gamma, beta, eps, tgt, loss_scale,
                                       loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
-    if (dgamma || dbeta) {
+    if (dgamma || dbeta || dysum) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
-                           dbeta, accumulate);
+                           dbeta, dysum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
     return UNITE_OK;

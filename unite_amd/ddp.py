@@ -40,6 +40,8 @@ class GradReducer:
         self.tag_bucket: Dict[Hashable, int] = {t: i for i, b in enumerate(self.buckets) for t in b["tags"]}
         self.use_stream = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
+        # RCCL ('nccl') averages in the collective; gloo (CPU tests, single-GPU rehearsal) has no AVG: sum, then scale
+        self.native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._pending: List[set] = []
         self._works = []
         self.reset()
@@ -62,7 +64,7 @@ class GradReducer:
             return
         b = self.buckets[i]
         view = self.grad[b["lo"]:b["hi"]]
-        if self.use_stream:
+        if self.use_stream and self.native_avg:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
@@ -78,7 +80,7 @@ class GradReducer:
             if p:            # a layer never reported (e.g. unused parameters): reduce what is there
                 self._pending[i] = set()
                 self._launch(i)
-        if self.use_stream:
+        if self.use_stream and self.native_avg:
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
             for w, view in self._works:

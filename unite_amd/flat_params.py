@@ -80,6 +80,11 @@ class FlatParams:
         o, k = self.qkv_bias[attn_prefix]
         return self.param[o:o + k]
 
+    def packed_qkv_bias_grad(self, attn_prefix: str) -> torch.Tensor:
+        """f32 [3*D] gradient view matching packed_qkv_bias (the middle third must stay zero)."""
+        o, k = self.qkv_bias[attn_prefix]
+        return self.grad[o:o + k]
+
     def g(self, name: str) -> torch.Tensor:
         """fp32 gradient view of a parameter."""
         return self._gview[name]

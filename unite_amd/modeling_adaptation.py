@@ -300,21 +300,23 @@ class _StudentRuntime:
             dy = ws.bufs[f"dec.dy{k}"]
             dxn = ws.get(f"dec.dxn{k}", (M, D), BF16)
             ops.gemm(dy, d["w"], dxn, trans_b=True)
-            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dy, d["gb"], csws, accumulate=acc)
+            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)      # head bias grad: dysum of the tail
         if self.layer_done_hook is not None:
             self.layer_done_hook("clip_decoder")
         norm_first = [True]
 
-        def tap_grad(li, dx_in, scale):
-            """adds d/dx_out(li) of the shared encoder.norm branch of tap li; returns (dx f32, dx bf16 * scale)."""
+        def tap_grad(li, dx_in, scale, dxsum):
+            """adds d/dx_out(li) of the shared encoder.norm branch of tap li; returns (dx f32, dx bf16 * scale) and writes the
+            column sums of the bf16 copy (= fc2 bias gradient of block li) into dxsum."""
             k = self.taps.index(li)
             t = self._tap[k]
             out = ws.get(f"bw.dxt{li & 1}", (M, D), F32)
             outb = ws.get("bw.dxtb", (M, D), BF16)
             ops.layernorm_bwd(ws.bufs[f"dec.dxn{k}"], t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
-                              dx_bf16=outb, row_scale=scale, rows_per_scale=N, dgamma=self.g_norm_w, dbeta=self.g_norm_b,
-                              accumulate=(acc or not norm_first[0]), workspace=lnws)
+                              dx_bf16=outb, row_scale=scale, rows_per_scale=N, workspace=lnws,
+                              dgamma=self.g_norm_w, dbeta=self.g_norm_b, dxsum=dxsum,
+                              # encoder.norm's gamma/beta ADD over the taps (bit 0); the bias column sums follow zero_grad (bit 1)
+                              accumulate=(1 if (acc or not norm_first[0]) else 0) | (2 if acc else 0))
             norm_first[0] = False
             if li == min(self.taps) and self.layer_done_hook is not None:
                 self.layer_done_hook("norm")      # encoder.norm's gradient is complete after the lowest tap
@@ -331,20 +333,18 @@ class _StudentRuntime:
             norm_first[0] = False
         s_last = None if dp is None else dp[last, 1]
         if last in self.taps:
-            dx, dxb = tap_grad(last, dx_top, s_last)
+            dx, dxb = tap_grad(last, dx_top, s_last, r._blk[last]["g:mlp.fc2.bias"])
         else:
             raise NotImplementedError("the last executed block must be a tap or carry an x_vis gradient")
 
-        def hook(li, dx_in, dxb_in, scale):
-            if li in self.taps:
-                return tap_grad(li, dx_in, scale)
-            return dx_in, dxb_in
+        def hook(li, dx_in, scale, dxsum):
+            return tap_grad(li, dx_in, scale, dxsum)
 
         def done(i):
             if self.layer_done_hook is not None:
                 self.layer_done_hook(i)
 
-        dx0, dx0b = r.blocks_backward(dx, dxb, ctx["n_blocks"], tap_hook=hook, layer_done=done)
+        dx0, dx0b = r.blocks_backward(dx, dxb, ctx["n_blocks"], tap_layers=set(self.taps), tap_hook=hook, layer_done=done)
         r.embed_backward(dx0b)
         if self.layer_done_hook is not None:
             self.layer_done_hook("patch_embed")
@@ -388,7 +388,7 @@ class _StudentFn(torch.autograd.Function):
                 dy.zero_()
                 continue
             ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout[k].contiguous().view(M, C), dy,
-                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate)
+                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, dysum=d["gb"])
         rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D))
         return None, None, None, None, None, None
 
@@ -422,7 +422,7 @@ class _StudentLossFn(torch.autograd.Function):
             d = rt.dec[k]
             dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
             ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, ctx.targets[k], 1.0 / float(K * M), None, dy,
-                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, loss_scale_dev=g)
+                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, loss_scale_dev=g, dysum=d["gb"])
         rt.backward_from_dy(None)
         return None, None, None, None, None, None
 

@@ -34,6 +34,13 @@ def _req(t: torch.Tensor, dtype, name: str):
         raise ValueError(f"{name}: last dim must be contiguous")
 
 
+def _acc_bits(accumulate) -> int:
+    """bool -> both outputs groups; int -> bit 0: gamma/beta gradients, bit 1: bias column sums"""
+    if isinstance(accumulate, bool):
+        return 3 if accumulate else 0
+    return int(accumulate)
+
+
 def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
 
@@ -93,12 +100,13 @@ def layernorm_bwd_workspace(M: int, D: int) -> int:
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, *, dx_residual=None, dx_out=None, dx_bf16=None, row_scale=None,
-                  rows_per_scale: int = 1, dgamma=None, dbeta=None, accumulate: bool = False, workspace: torch.Tensor = None):
+                  rows_per_scale: int = 1, dgamma=None, dbeta=None, dxsum=None, accumulate: bool = False,
+                  workspace: torch.Tensor = None):
     lib = _lib.load()
     M, D = x.shape
     _lib.check(lib.unite_layernorm_bwd(_ptr(dy), int(dy.dtype == F32), _ptr(x), x.stride(0), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                        _ptr(dx_residual), _ptr(dx_out), _ptr(dx_bf16), _ptr(row_scale), rows_per_scale,
-                                       _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace), M, D, _stream()),
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), _acc_bits(accumulate), _ptr(workspace), M, D, _stream()),
                "unite_layernorm_bwd")
 
 
@@ -106,11 +114,12 @@ def colsum_workspace(M: int, N: int) -> int:
     return int(_lib.load().unite_colsum_workspace(M, N))
 
 
-def colsum(x: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, accumulate: bool = False):
+def colsum(x: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, accumulate: bool = False, zero_range=(0, 0)):
     lib = _lib.load()
     _req(x, BF16, "x")
     M, N = x.shape
-    _lib.check(lib.unite_colsum_bf16(_ptr(x), x.stride(0), M, N, _ptr(out), int(accumulate), _ptr(workspace), _stream()),
+    _lib.check(lib.unite_colsum_bf16(_ptr(x), x.stride(0), M, N, _ptr(out), int(accumulate), zero_range[0], zero_range[1],
+                                     _ptr(workspace), _stream()),
                "unite_colsum_bf16")
     return out
 
@@ -198,11 +207,11 @@ def decoder_tail_fwd(y, gamma, beta, eps: float, tgt, out, loss_sum):
 
 
 def decoder_tail_bwd(y, gamma, beta, eps: float, tgt, loss_scale: float, dout, dy_bf16, dgamma, dbeta, workspace,
-                     accumulate: bool = False, loss_scale_dev=None):
+                     accumulate: bool = False, loss_scale_dev=None, dysum=None):
     lib = _lib.load()
     M, Cd = y.shape
     _lib.check(lib.unite_decoder_tail_bwd(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(tgt), loss_scale, _ptr(loss_scale_dev), _ptr(dout), _ptr(dy_bf16),
-                                          _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace), M, Cd, _stream()),
+                                          _ptr(dgamma), _ptr(dbeta), _ptr(dysum), _acc_bits(accumulate), _ptr(workspace), M, Cd, _stream()),
                "unite_decoder_tail_bwd")
 
 

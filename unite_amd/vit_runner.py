@@ -93,6 +93,7 @@ class ViTRunner:
                 d[n] = fp.w16(pre + b + n)
                 d["g:" + n] = fp.g(pre + b + n)
             d["qkv_bias"] = fp.packed_qkv_bias(pre + b + "attn.")        # (q_bias, 0, v_bias), modeling_finetune.py:104
+            d["g:qkv_bias"] = fp.packed_qkv_bias_grad(pre + b + "attn.")
             self._blk.append(d)
         self._pe_w = fp.w16(pre + "patch_embed.proj.weight")
         self._pe_b = P("patch_embed.proj.bias")
@@ -163,11 +164,12 @@ class ViTRunner:
         return xs
 
     # ------------------------------------------------------------------ backward
-    def blocks_backward(self, dx: torch.Tensor, dxb: torch.Tensor, n_blocks: int, tap_hook=None, layer_done=None):
-        """dx: f32 [M,D] gradient w.r.t. x_out(n_blocks-1); dxb: its bf16 copy already multiplied by the
-        drop-path scale of that block's MLP branch.  tap_hook(i, dx, dxb_out, scale) is called when the gradient
-        w.r.t. x_out(i-1) is complete except for a tap contribution (it must add it and return the final (dx, dxb)).
-        Writes every block's parameter gradients; returns (dx0 f32, dx0 bf16 unscaled) w.r.t. the block-0 input."""
+    def blocks_backward(self, dx: torch.Tensor, dxb: torch.Tensor, n_blocks: int, tap_layers=(), tap_hook=None, layer_done=None):
+        """dx: f32 [M,D] gradient w.r.t. x_out(n_blocks-1); dxb: its bf16 copy already multiplied by the drop-path scale of
+        that block's MLP branch (whoever produced dxb also produced its column sums = the fc2 bias gradient).
+        For i-1 in tap_layers, tap_hook(i-1, dx, scale, dxsum) must add the tap's gradient to dx and return the final
+        (dx, dxb) for block i-1 (and write dxsum = column sums of dxb).  Writes every block's parameter gradients and the
+        patch-embed bias gradient; returns (dx0 f32, dx0 bf16 unscaled) w.r.t. the block-0 input."""
         fw = self._fw
         B, N, dp = fw["B"], fw["N"], fw["dp"]
         D, H, Hd, ws, fp = self.D, self.H, self.Hd, self.ws, self.fp
@@ -182,7 +184,6 @@ class ViTRunner:
             dz = ws.get("bw.dz", (M, Hd), BF16)
             ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
             ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dxb, w["g:mlp.fc2.bias"], csws, accumulate=acc)
             dh2 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
             ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
@@ -191,31 +192,33 @@ class ViTRunner:
             dx1b = ws.get("bw.dx1b", (M, D), BF16)
             ops.layernorm_bwd(dh2, s["x1"], s["mean2"], s["rstd2"], w["norm2.weight"], dx_residual=dx, dx_out=dx1, dx_bf16=dx1b,
                               row_scale=None if dp is None else dp[i, 0], rows_per_scale=N,
-                              dgamma=w["g:norm2.weight"], dbeta=w["g:norm2.bias"], accumulate=acc, workspace=lnws)
+                              dgamma=w["g:norm2.weight"], dbeta=w["g:norm2.bias"], dxsum=w["g:attn.proj.bias"],
+                              accumulate=acc, workspace=lnws)
             # ---- attention branch
             do = ws.get("bw.do", (M, D), BF16)
             ops.gemm(dx1b, w["attn.proj.weight"], do, trans_b=True)
             ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dx1b, w["g:attn.proj.bias"], csws, accumulate=acc)
             dqkv = ws.get("bw.dqkv", (M, 3 * D), BF16)
             delta = ws.get("bw.delta", (B, H, N), F32)
             ops.attn_bwd(s["qkv"], s["o"], do, s["lse"], delta, dqkv, B, N, H, self.scale)
             dh1 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
             ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dqkv[:, :D], w["g:attn.q_bias"], csws, accumulate=acc)
-            ops.colsum(dqkv[:, 2 * D:], w["g:attn.v_bias"], csws, accumulate=acc)
+            ops.colsum(dqkv, w["g:qkv_bias"], csws, accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
             # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
             # branch's drop-path factor) or the patch-embed weight gradient (unscaled)
             dx0 = ws.get(f"bw.dx{i & 1}", (M, D), F32)
             dx0b = ws.get("bw.dxb", (M, D), BF16)
             nxt_scale = None if (dp is None or i == 0) else dp[i - 1, 1]
-            ops.layernorm_bwd(dh1, s["x_in"], s["mean1"], s["rstd1"], w["norm1.weight"], dx_residual=dx1, dx_out=dx0, dx_bf16=dx0b,
-                              row_scale=nxt_scale, rows_per_scale=N,
-                              dgamma=w["g:norm1.weight"], dbeta=w["g:norm1.bias"], accumulate=acc, workspace=lnws)
+            nxt_bias_g = self._blk[i - 1]["g:mlp.fc2.bias"] if i > 0 else self._pe_gb
+            tapped = i > 0 and (i - 1) in tap_layers      # the tap hook then emits the final bf16 copy and its column sums
+            ops.layernorm_bwd(dh1, s["x_in"], s["mean1"], s["rstd1"], w["norm1.weight"], dx_residual=dx1, dx_out=dx0,
+                              dx_bf16=None if tapped else dx0b, row_scale=nxt_scale, rows_per_scale=N,
+                              dgamma=w["g:norm1.weight"], dbeta=w["g:norm1.bias"], dxsum=None if tapped else nxt_bias_g,
+                              accumulate=acc, workspace=lnws)
             dx, dxb = dx0, dx0b
-            if tap_hook is not None and i > 0:
-                dx, dxb = tap_hook(i - 1, dx, dxb, nxt_scale)
+            if tapped:
+                dx, dxb = tap_hook(i - 1, dx, nxt_scale, nxt_bias_g)
             if layer_done is not None:
                 layer_done(i)
         return dx, dxb
@@ -227,5 +230,4 @@ class ViTRunner:
         M = cols.shape[0]
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(self.Hd, 3 * D)))
         ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate,
-                 workspace=ws.bytes_("gemm.ws", SPLITK_WS_BYTES))
-        ops.colsum(dxb, self._pe_gb, csws, accumulate=fp.accumulate)
+                 workspace=ws.bytes_("gemm.ws", SPLITK_WS_BYTES))      # the bias gradient came with dxb (blocks_backward)
