@@ -34,7 +34,8 @@ struct Params {
     uint32_t a_bytes, b_bytes;
     int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
     float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
-    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue stores; 2: no MFMA)
+    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
+    int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -137,11 +138,17 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
         }
-        *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-        *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        if (p.nt_store) {
+            __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, (f32x4*)op);
+            __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, (f32x4*)(op + 4));
+        } else {
+            *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
     } else {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+        if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
+        else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
     }
     if (g.out_bf16_copy) {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
@@ -257,12 +264,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
 __device__ __forceinline__ int swz128t(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }   // 32-B chunk swizzle of [k][64] images
 
 // one 1-KiB LDS-DMA piece `it` of a half-tile image (HALF rows/cols x 64 k)
-template <bool TR, int HALF>
+__device__ __forceinline__ int swzperm(int n) { return ((n >> 1) & 1) | (((n >> 4) & 3) << 1); }   // for rows read as 16g + 4j + r
+
+template <bool TR, int HALF, bool PERM = false>
 __device__ __forceinline__ void stage_piece(__amdgpu_buffer_rsrc_t rs, char* slot, int it, int r0, int k0, int R, int K, int ld, int lane) {
     uint32_t voff;
     if (!TR) {                                   // image [HALF][64 k], 128-B rows, 16-B chunk c at c ^ (row & 7)
         const int r = it * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ (r & 7);
+        const int lc = (lane & 7) ^ (PERM ? swzperm(r) : (r & 7));
         const int gr = r0 + r, gk = k0 + lc * 8;
         voff = (gr < R && gk < K) ? (uint32_t)(gr * ld + gk) * 2u : OOB_OFFSET;
     } else if (HALF == 128) {                    // image [64 k][128], 256-B rows, swz256
@@ -289,6 +298,28 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* slot, int row0, int ks
     const s16x4 hi = lds_read_tr16(slot + 128 * k_hi + ((c32 ^ swz128t(k_hi)) << 5) + 8 * pp);
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
+}
+
+// B fragment of the wide kernel with the n <-> MFMA-row permutation  n = bcol + 16 (rho >> 2) + 4 j + (rho & 3):
+// with the operands swapped (C^T in the accumulators) lane group G then holds 16 CONSECUTIVE columns over the wave's four
+// n-tiles, i.e. 64 B (f32) / 32 B (bf16) per lane and 256 B / 128 B contiguous per output row: the epilogue stores
+// straight from the registers (no LDS round trip, which would compete with the co-resident workgroup's main loop).
+template <bool TR>
+__device__ __forceinline__ bf16x8 load_bfrag_perm(const char* slot, int bcol, int j, int ks, int lane) {
+    if (!TR) {
+        const int rho = lane & 15;
+        const int n = bcol + 16 * (rho >> 2) + 4 * j + (rho & 3);
+        const int lc = ks * 4 + (lane >> 4);
+        return *(const bf16x8*)(slot + n * 128 + ((lc ^ swzperm(n)) << 4));
+    } else {
+        const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int ch = (bcol >> 3) + 2 * pp + (j >> 1);
+        const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
+        const s16x4 lo = lds_read_tr16(slot + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (j & 1));
+        const s16x4 hi = lds_read_tr16(slot + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (j & 1));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
 }
 
 template <int HALF, bool TA, bool TB>
@@ -460,6 +491,208 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     }
 }
 
+// =====================================================================================================================
+// "Wide" kernel: 128 x 256 x 64 tile, 4 waves (2 x 2), TWO workgroups per CU (64 KiB of LDS each), so one workgroup's
+// store-heavy epilogue overlaps the other's MFMA main loop.  Same quadrant schedule as the deep kernel (16 MFMAs per phase
+// and wave: A half = 64 rows -> 2 m-tiles, B half = 128 columns -> 4 n-tiles per wave), but with a SINGLE K-tile of LDS
+// (A0 A1 8 KiB each, B0 B1 16 KiB each): a half-tile slot is refilled for the next K-tile right after the phase that read
+// it, i.e. every load is in flight for three phases:
+//   P1: wait vmcnt(6)  reads A0,B0            MFMA (0,0)
+//   P2: wait vmcnt(2)  reads B1   issues A0',B0'   MFMA (0,1)
+//   P3: wait vmcnt(6)  reads A1   issues B1'       MFMA (1,1)
+//   P4:                           issues A1'       MFMA (1,0)      (each phase starts with a raw s_barrier)
+// =====================================================================================================================
+constexpr int WIDE_LDS = 64 * 256 * 4;       // 64 KiB: the ring uses 48 KiB, the epilogue image (64 rows x 256 f32) all of it
+
+template <bool TA, bool TB, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 128, TN = 256;
+    const unite_gemm_args& g = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbn = (g.N + TN - 1) / TN, nbm = (g.M + TM - 1) / TM, nb = nbm * nbn, nbt = nb * p.splitk;
+    const int bid = blockIdx.x, xcd = bid & 7, qq = nbt >> 3, rr = nbt & 7;
+    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile = lin % nb, slice = lin / nb;
+    const int m0 = (tile / nbn) * TM, n0 = (tile % nbn) * TN;
+    const int k_begin = slice * p.k_chunk, k_end = min(g.K, k_begin + p.k_chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)p.b_bytes, 0x00020000);
+    char* const A0 = smem;
+    char* const A1 = smem + 8192;
+    char* const B0 = smem + 16384;
+    char* const B1 = smem + 32768;
+
+    auto issueA = [&](char* slot, int h, int u) {      // 64 rows x 64 k = 8 pieces, 2 per wave
+        const int k0 = k_begin + u * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) stage_piece<TA, 64>(rsA, slot, wave * 2 + i, m0 + h * 64, k0, g.M, k_end, g.lda, lane);
+    };
+    auto issueB = [&](char* slot, int nh, int u) {     // 128 cols x 64 k = 16 pieces, 4 per wave
+        const int k0 = k_begin + u * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_piece<TB, 128, DIRECT>(rsB, slot, wave * 4 + i, n0 + nh * 128, k0, g.N, k_end, g.ldb, lane);
+    };
+
+    f32x4 acc[2][2][2][4];       // [A half][m-tile][B half][n-tile]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][nh][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issueA(A0, 0, 0);
+    issueB(B0, 0, 0);
+    issueB(B1, 1, 0);
+    issueA(A1, 1, 0);
+    f32x4 bias0, bias1;
+    if (!DIRECT) load_bias8(g, n0 + (tid & 31) * 8, bias0, bias1);
+
+    const int arow = wm * 32, bcol = wn * 64;
+    for (int t = 0; t < nk; ++t) {
+        bf16x8 af[2][2], b0f[4][2], b1f[4][2];
+        // ---- P1
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, 64>(A0, arow + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b0f[j][ks] = DIRECT ? load_bfrag_perm<TB>(B0, bcol, j, ks, lane) : load_frag_h<TB, 128>(B0, bcol + j * 16, ks, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0][i][0][j] = DIRECT ? mfma16(b0f[j][ks], af[i][ks], acc[0][i][0][j]) : mfma16(af[i][ks], b0f[j][ks], acc[0][i][0][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- P2
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b1f[j][ks] = DIRECT ? load_bfrag_perm<TB>(B1, bcol, j, ks, lane) : load_frag_h<TB, 128>(B1, bcol + j * 16, ks, lane);
+        issueA(A0, 0, t + 1);
+        issueB(B0, 0, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0][i][1][j] = DIRECT ? mfma16(b1f[j][ks], af[i][ks], acc[0][i][1][j]) : mfma16(af[i][ks], b1f[j][ks], acc[0][i][1][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- P3
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, 64>(A1, arow + i * 16, ks, lane);
+        issueB(B1, 1, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[1][i][1][j] = DIRECT ? mfma16(b1f[j][ks], af[i][ks], acc[1][i][1][j]) : mfma16(af[i][ks], b1f[j][ks], acc[1][i][1][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- P4 (the barrier orders every wave's phase-3 reads of A1 before its refill)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issueA(A1, 1, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[1][i][0][j] = DIRECT ? mfma16(b0f[j][ks], af[i][ks], acc[1][i][0][j]) : mfma16(af[i][ks], b0f[j][ks], acc[1][i][0][j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.debug_skip == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[h][i][nh][j]));
+        return;
+    }
+
+    const int G = lane >> 4, c16 = lane & 15;
+    if (DIRECT) {
+        // ---- epilogue from the registers: lane (G, c16) owns row c16 of each m-tile and 16 consecutive columns per B half
+        f32x4 bb[2][4];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            load_bias8(g, n0 + nh * 128 + bcol + 16 * G, bb[nh][0], bb[nh][1]);
+            load_bias8(g, n0 + nh * 128 + bcol + 16 * G + 8, bb[nh][2], bb[nh][3]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int gm = m0 + h * 64 + arow + i * 16 + c16;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int gn = n0 + nh * 128 + bcol + 16 * G;
+                    if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, acc[h][i][nh][0], acc[h][i][nh][1], bb[nh][0], bb[nh][1]);
+                    if (gm < g.M && gn + 8 < g.N) epilogue_chunk(p, slice, gm, gn + 8, acc[h][i][nh][2], acc[h][i][nh][3], bb[nh][2], bb[nh][3]);
+                }
+            }
+        return;
+    }
+    // ---- epilogue: 64 rows x 256 columns per pass through an f32 image, 8 chunks of 8 columns per thread
+    float* cs = (float*)smem;
+    const int ccol = (tid & 31) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(arow + i * 16 + 4 * G + r) * TN + nh * 128 + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
+        __syncthreads();
+#pragma unroll 2
+        for (int e = 0; e < 8; ++e) {
+            const int lr = (tid >> 5) + e * 8;
+            const int gm = m0 + h * 64 + lr, gn = n0 + ccol;
+            if (gm < g.M && gn < g.N)
+                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * TN + ccol), *(const f32x4*)(cs + lr * TN + ccol + 4), bias0, bias1);
+        }
+        __syncthreads();
+    }
+}
+
 // out[m,n] (+)= sum_s slab[s][m,n]  -- fixed summation order, so weight gradients are bitwise reproducible
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splitk, int M, int N, float* __restrict__ out,
                                                             int ldc, int accumulate) {
@@ -482,19 +715,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Split-K factor for short-and-wide problems (weight gradients: M x N = 768..3072 square-ish, K = tokens): choose the
-// slice count that minimises  waves(tiles * S over 512 resident workgroups) * (K/S + fixed cost), S <= 16.
-inline int choose_splitk(int tiles, int K, size_t slab_bytes_per_slice, size_t ws_bytes) {
-    if (tiles >= 384 || K < 1024) return 1;
-    int best = 1;
-    double best_cost = 1e30;
-    for (int S = 1; S <= 16; ++S) {
-        if ((size_t)S * slab_bytes_per_slice > ws_bytes && S > 1) break;
-        const int kc = ((K + S - 1) / S + BK - 1) / BK * BK;
-        if (S > 1 && kc < 256) break;
-        const double waves = (double)((tiles * S + 511) / 512);
-        const double cost = waves * (kc + 320.0) + (S > 1 ? 40.0 * S : 0.0);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+// Joint choice of kernel and split-K factor from a cost model fitted on MI355X (us):
+//   time(kind, S) = rounds(tiles(kind) * S over resident workgroups) * (ceil(K-tiles / S) * c + e) + slab reduction,
+// kind 1: 128^2 tile, 512 resident (2 / CU), (c, e) = (1.006, 4.4);  kind 2: 256^2, 256 resident, (1.51, 9.8);
+// kind 3: 128 x 256, 512 resident, (1.58, 9.0).  S > 1 only for plain f32 outputs with a workspace (weight gradients).
+struct Plan { int kind, splitk; double cost; };
+inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind) {
+    const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
+    const int slots[4] = {0, 512, 256, 512};
+    const double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
+    const int kt = (K + BK - 1) / BK;
+    Plan best = {1, 1, 1e30};
+    for (int kind = 1; kind <= 3; ++kind) {
+        if (only_kind && kind != only_kind) continue;
+        for (int S = 1; S <= 16; ++S) {
+            if (S > 1 && (!can_split || (size_t)S * M * N * sizeof(float) > ws_bytes || kt / S < 4)) break;
+            const int kts = (kt + S - 1) / S;
+            const double rounds = (double)((tiles[kind] * S + slots[kind] - 1) / slots[kind]);
+            double cost = rounds * (kts * cc[kind] + ee[kind]);
+            if (S > 1) cost += 3.0 + (double)S * M * N * 8.0 / 5.0e6;      // slab write + read at ~5 TB/s, one more launch
+            if (cost < best.cost - 1e-9) best = {kind, S, cost};
+        }
     }
     return best;
 }
@@ -531,42 +772,46 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     p.a = g;
     p.a_bytes = (uint32_t)a_bytes;
     p.b_bytes = (uint32_t)b_bytes;
-    // kernel choice (UNITE_GEMM_KERNEL = simple | deep128 | deep256 overrides): estimated time = rounds x (K-tiles x c + e)
-    // with (c, e) per kernel measured on MI355X (rounds = tiles over resident workgroups); see DESIGN.md.
+    // kernel + split-K choice; UNITE_GEMM_KERNEL = simple | deep128 | deep256 | wide pins the kernel (A/B experiments)
     static const char* force = getenv("UNITE_GEMM_KERNEL");
-    const int t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    int kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2
-    if (force) kind = !strcmp(force, "simple") ? 0 : !strcmp(force, "deep256") ? 2 : 1;
-    else {
-        // time ~ rounds x (K-tiles x c + e), (c, e) in us fitted on MI355X: 128^2 tile (2 workgroups / CU): c 1.006, e 4.4;
-        // 256^2 tile (1 / CU): c 1.51, e 9.8.  The wide tile wins when N is large enough to keep its last round full.
-        const double kt = (double)((g.K + BK - 1) / BK);
-        const double c128 = (double)((t128 + 511) / 512) * (kt * 1.006 + 4.4);
-        const double c256 = (double)((t256 + 255) / 256) * (kt * 1.51 + 9.8);
-        kind = c256 < c128 ? 2 : 1;
-    }
-    const int tiles = kind == 2 ? t256 : t128;
+    const int only = !force ? 0 : !strcmp(force, "deep256") ? 2 : !strcmp(force, "wide") ? 3 : 1;
+    const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
+    const bool can_split = plain && g.workspace && aligned16(g.workspace);
+    const Plan plan = plan_gemm(g.M, g.N, g.K, can_split, (size_t)g.workspace_bytes, only);
+    const int kind = (force && !strcmp(force, "simple")) ? 0 : plan.kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2, 3 wide
+    const int tiles = kind == 2 ? ((g.M + 255) / 256) * ((g.N + 255) / 256)
+                    : kind == 3 ? ((g.M + 127) / 128) * ((g.N + 255) / 256) : ((g.M + 127) / 128) * ((g.N + 127) / 128);
     p.splitk = 1;
     p.k_chunk = (g.K + BK - 1) / BK * BK;
     p.slab = nullptr;
     static const int dbg = getenv("UNITE_GEMM_DEBUG_SKIP") ? atoi(getenv("UNITE_GEMM_DEBUG_SKIP")) : 0;
     p.debug_skip = dbg;
-    const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
-    if (plain && g.workspace && aligned16(g.workspace)) {
-        const size_t per_slice = (size_t)g.M * g.N * sizeof(float);
-        const int S = choose_splitk(tiles, g.K, per_slice, (size_t)g.workspace_bytes);
-        if (S > 1) {
-            p.splitk = S;
-            p.k_chunk = ((g.K + S - 1) / S + BK - 1) / BK * BK;
-            p.splitk = (g.K + p.k_chunk - 1) / p.k_chunk;      // drop empty trailing slices
-            p.slab = (float*)g.workspace;
-        }
+    static const int nt = getenv("UNITE_GEMM_NT") ? atoi(getenv("UNITE_GEMM_NT")) : 0;
+    p.nt_store = nt;
+    if (plan.splitk > 1) {
+        p.k_chunk = ((g.K + plan.splitk - 1) / plan.splitk + BK - 1) / BK * BK;
+        p.splitk = (g.K + p.k_chunk - 1) / p.k_chunk;      // drop empty trailing slices
+        p.slab = (float*)g.workspace;
     }
     const int nb = tiles * p.splitk;
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
-    if (kind == 2) {
+    if (kind == 3) {
+        // register-direct epilogue measured slower than the LDS-staged one (narrower stores): opt-in for experiments only
+        static const bool direct = getenv("UNITE_GEMM_WIDE_DIRECT") && atoi(getenv("UNITE_GEMM_WIDE_DIRECT"));
+        if (direct) {
+            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<false, false, true>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<false, true, true>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<true, false, true>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else hipLaunchKernelGGL((gemm_wide_kernel<true, true, true>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+        } else {
+            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<false, false, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<false, true, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<true, false, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+            else hipLaunchKernelGGL((gemm_wide_kernel<true, true, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
+        }
+    } else if (kind == 2) {
         static bool lds_ok = false;
         if (!lds_ok) {
             const void* ks[4] = {(const void*)gemm_deep_kernel<128, false, false>, (const void*)gemm_deep_kernel<128, false, true>,

@@ -171,34 +171,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 }
 
 // out_k[c] (+)= sum_b partial[b][k][c], k = 0..2; fixed order -> deterministic.
-// One workgroup per 64 columns: thread (r, c) = (tid>>6, tid&63) sums partial rows r, r+4, ... (256-B coalesced row
-// segments), then the four row groups are combined through LDS in a fixed order.
+// One workgroup per 16 columns (D/16 workgroups): thread (r, c) = (tid >> 4, tid & 15) sums partial rows r, r+16, ...,
+// then the 16 row groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* __restrict__ out_a, float* __restrict__ out_b, float* __restrict__ out_c,
                                                               int accumulate) {
-    __shared__ float red[3][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    __shared__ float red[3][16][17];
+    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float a = 0.f, b = 0.f, d = 0.f;
     if (c < D) {
-        for (int i = r; i < nblocks; i += 4) {
+        for (int i = r; i < nblocks; i += 16) {
             a += partial[((size_t)i * 3 + 0) * D + c];
             b += partial[((size_t)i * 3 + 1) * D + c];
             d += partial[((size_t)i * 3 + 2) * D + c];
         }
     }
-    red[0][r][threadIdx.x & 63] = a;
-    red[1][r][threadIdx.x & 63] = b;
-    red[2][r][threadIdx.x & 63] = d;
+    red[0][r][cl] = a;
+    red[1][r][cl] = b;
+    red[2][r][cl] = d;
     __syncthreads();
-    if (r == 0 && c < D) {
-        const int l = threadIdx.x;
-        a = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-        b = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-        d = red[2][0][l] + red[2][1][l] + red[2][2][l] + red[2][3][l];
-        // accumulate: bit 0 -> out_a/out_b (gamma/beta gradients), bit 1 -> out_c (bias column sums)
-        if (out_a) out_a[c] = (accumulate & 1) ? out_a[c] + a : a;
-        if (out_b) out_b[c] = (accumulate & 1) ? out_b[c] + b : b;
-        if (out_c) out_c[c] = (accumulate & 2) ? out_c[c] + d : d;
+    if (threadIdx.x < 48) {
+        const int k = threadIdx.x >> 4, cc = blockIdx.x * 16 + cl;
+        if (cc < D) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v += red[k][i][cl];
+            float* out = k == 0 ? out_a : (k == 1 ? out_b : out_c);
+            // accumulate: bit 0 -> out_a/out_b (gamma/beta gradients), bit 1 -> out_c (bias column sums)
+            const int acc = k < 2 ? (accumulate & 1) : (accumulate & 2);
+            if (out) out[cc] = acc ? out[cc] + v : v;
+        }
     }
 }
 
@@ -454,7 +457,7 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     UNITE_LAUNCH_CHECK();
     if (dxsum && !dx_bf16) return UNITE_EINVAL;
     if (dgamma || dbeta || dxsum) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
                            dbeta, dxsum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
@@ -481,7 +484,7 @@ extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const 
                                       loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta || dysum) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
                            dbeta, dysum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
