@@ -181,8 +181,12 @@ def main():
         lib.unite_prof_enable(0, 0)
         print(f"[bench] profiled pass: {cnt.value} GEMM launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12,
-                "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None,
+        traffic = None      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same command
+        tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tp):
+            traffic = round(json.load(open(tp))["traffic_bytes_per_launch"])
+        roof = {"bound": "mfma", "kernel": "gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues)", "achieved": round(ach, 1),
+                "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),

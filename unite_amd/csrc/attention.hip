@@ -85,11 +85,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         for (int kt = 0; kt < NT16; ++kt) {
             f32x4 s = mfma16(row_frag(Ks, kt * 16, 0, lane), qf0, (f32x4){0.f, 0.f, 0.f, 0.f});
             s = mfma16(row_frag(Ks, kt * 16, 1, lane), qf1, s);
+            if (kt * 16 + 16 > N) {      // wave-uniform: only the tile(s) straddling / beyond N need the key mask
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 4 * G + r >= N) s[r] = -INFINITY;
-                m = fmaxf(m, s[r]);
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * G + r >= N) s[r] = -INFINITY;
             }
+            m = fmaxf(fmaxf(m, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
             st[kt] = s;
         }
         m = group_max(m);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         for (int kt = 0; kt < NT16; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f((st[kt][r] - m) * sl2);
+                const float p = __builtin_amdgcn_exp2f((st[kt][r] - m) * sl2);      // v_exp_f32; exp2(-inf) = 0 for masked keys
                 st[kt][r] = p;
                 sum += p;
             }
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                 dp = mfma16(row_frag(Vs, kt * 16, 1, lane), df1, dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (kt * 16 + 4 * G + r < N) ? exp2f(s[r] * sl2 - l2) : 0.f;
+                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l2);
+                    if (kt * 16 + 16 > N && kt * 16 + 4 * G + r >= N) p = 0.f;      // keys beyond N (boundary tiles only)
                     ds[t][r] = p * (dp[r] - dl);
                 }
             }
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 dp = mfma16(da1, vf[i][1], dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (q0 + 4 * G + r < N) ? exp2f(s[r] * sl2 - l4[r]) : 0.f;
+                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]);
+                    if (q0 + 16 > N && q0 + 4 * G + r >= N) p = 0.f;                 // query rows beyond N (boundary tiles only)
                     P[t][i][r] = p;
                     dS[t][i][r] = p * (dp[r] - d4[r]);
                 }

@@ -138,7 +138,12 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
         }
-        if (p.nt_store) {
+        if (p.nt_store == 2) {       // write-through, line dropped from the XCD's L2 (sc1): the output must not evict A/B panels
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
+            const uint32_t off = (uint32_t)(((size_t)gm * g.ldc + gn) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, ro, off + 16, 0, 16);
+        } else if (p.nt_store) {
             __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, (f32x4*)op);
             __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, (f32x4*)(op + 4));
         } else {
@@ -147,7 +152,10 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int g
         }
     } else {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
+        if (p.nt_store == 2) {
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
+        } else if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
         else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
     }
     if (g.out_bf16_copy) {
@@ -786,8 +794,11 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     p.slab = nullptr;
     static const int dbg = getenv("UNITE_GEMM_DEBUG_SKIP") ? atoi(getenv("UNITE_GEMM_DEBUG_SKIP")) : 0;
     p.debug_skip = dbg;
-    static const int nt = getenv("UNITE_GEMM_NT") ? atoi(getenv("UNITE_GEMM_NT")) : 0;
-    p.nt_store = nt;
+    // Large bf16 outputs (e.g. 232-310 MB per teacher GEMM) are written through and dropped from the XCD L2 (sc1 stores):
+    // left in the L2 they evict the B operand, which every XCD then re-fetches each round (+3 % measured).  f32 outputs
+    // (32 B per lane) measured slower with sc1 and keep plain stores.  UNITE_GEMM_NT = 0 | 1 (nt) | 2 (sc1) overrides.
+    static const int nt = getenv("UNITE_GEMM_NT") ? atoi(getenv("UNITE_GEMM_NT")) : -1;
+    p.nt_store = nt >= 0 ? nt : ((!g.out_f32 && (size_t)g.M * g.N * 2 > (32u << 20)) ? 2 : 0);
     if (plan.splitk > 1) {
         p.k_chunk = ((g.K + plan.splitk - 1) / plan.splitk + BK - 1) / BK * BK;
         p.splitk = (g.K + p.k_chunk - 1) / p.k_chunk;      // drop empty trailing slices
