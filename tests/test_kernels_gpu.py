@@ -242,6 +242,49 @@ def test_attention_fwd_bwd(ops, B, N, H):
         assert (a - r).norm() <= 2e-2 * r.norm() + 1e-6, name
 
 
+@pytest.mark.parametrize("B,N,H", [(1, 321, 2), (2, 520, 1), (1, 1568, 2), (1, 3136, 1), (2, 100, 1)])
+def test_attention_tiled_fwd_bwd(ops, B, N, H):
+    """sequences beyond the whole-head-in-LDS kernels (stage 2/3 all-token passes): flash-style tiled kernels with online
+    softmax; N = 100 is forced through the tiled path by the env switch in a subprocess-free way (N > 320 selects it)."""
+    qkv = bf(rnd(B * N, 3 * H * 64, seed=N, scale=1.0))
+    qkv_g = qkv.float().clone().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(qkv_g, B, N, H)
+    do = bf(rnd(B * N, H * 64, seed=N + 1))
+    o_ref.backward(do.float())
+    qd = qkv.to(DEV)
+    out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qd, out, lse, B, N, H, 64 ** -0.5)
+    torch.testing.assert_close(out.float().cpu(), o_ref.detach(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), atol=2e-3, rtol=1e-4)
+    dqkv = torch.full((B * N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    ops.attn_bwd(qd, out, do.to(DEV), lse, delta, dqkv, B, N, H, 64 ** -0.5)
+    g = qkv_g.grad
+    assert torch.isfinite(dqkv.float()).all()
+    for i, name in enumerate("qkv"):
+        a = dqkv.float().cpu()[:, i * H * 64:(i + 1) * H * 64]
+        r = g[:, i * H * 64:(i + 1) * H * 64]
+        assert (a - r).norm() <= 2e-2 * r.norm() + 1e-6, name
+
+
+def test_attention_tiled_online_softmax_rescale(ops):
+    """the running max jumps late (a dominant key in the LAST tile): forces the O / l rescale branch of the online softmax"""
+    B, N, H = 1, 700, 1
+    qkv = rnd(B * N, 192, seed=5, scale=0.5)
+    qkv[3, :64] = 5.0
+    qkv[690, 64:128] = 5.0           # q3 . k690 = 64 * 25 / 8 = 200 in the last key tile
+    qkv[10, 64:128] = 2.0            # a smaller early maximum for the same query
+    qkv = bf(qkv)
+    o_ref, lse_ref, p = _attn_ref(qkv, B, N, H)
+    out = torch.empty(B * N, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qkv.to(DEV), out, lse, B, N, H, 64 ** -0.5)
+    assert p[0, 0, 3, 690] > 0.999
+    torch.testing.assert_close(out.float().cpu(), o_ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
+
+
 def test_attention_softmax_spike(ops):
     """One key dominates one query (large logit): exercises the exact full-row softmax with a huge max."""
     B, N, H = 1, 320, 1

@@ -14,46 +14,10 @@
 // One LDS image serves row reads (ds_read_b128) and transposed reads: 128-B rows, 32-B chunk c of row r stored at
 // chunk c ^ ((r>>1)&3); conflict-free for both access kinds.  Tiles are staged by LDS-DMA with the swizzle on the
 // source address; rows >= N read as zero through the buffer descriptor's range check.
-#include "common.h"
+#include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
-
-constexpr float LOG2E = 1.4426950408889634f;
-
-__device__ __forceinline__ int row_addr(int row, int c16) {   // byte offset of 16-B chunk c16 of `row`
-    return row * 128 + (((((c16 >> 1) ^ ((row >> 1) & 3)) << 1) | (c16 & 1)) << 4);
-}
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, int lane) {
-    return *(const bf16x8*)(tile + row_addr(row0 + (lane & 15), ks * 4 + (lane >> 4)));
-}
-// transposed fragment: element j = X[rows32 + (j<4 ? 4G+j : 16+4G+j-4)][16 dt + (l&15)]
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rows32, int dt, int lane) {
-    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int r_lo = rows32 + 4 * G + q, r_hi = r_lo + 16;
-    const s16x4 lo = lds_read_tr16(tile + r_lo * 128 + ((dt ^ ((r_lo >> 1) & 3)) << 5) + 8 * p);
-    const s16x4 hi = lds_read_tr16(tile + r_hi * 128 + ((dt ^ ((r_hi >> 1) & 3)) << 5) + 8 * p);
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
-    u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
-    return __builtin_bit_cast(bf16x8, w);
-}
-// stage rows [0, rows_padded) of one head slice (element offset base, row stride ld) into the swizzled image
-__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int rows_padded, int n_valid, uint32_t base, int ld,
-                                           int wave, int nwaves, int lane) {
-    for (int it = wave; it < rows_padded / 8; it += nwaves) {
-        const int r = it * 8 + (lane >> 3), p = lane & 7;
-        const int lc16 = ((((p >> 1) ^ ((r >> 1) & 3)) << 1) | (p & 1));
-        const uint32_t voff = (r < n_valid) ? (base + (uint32_t)r * ld + lc16 * 8) * 2u : OOB_OFFSET;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(tile + it * 1024), 16, voff, 0, 0, 0);
-    }
-}
-__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ void store_bf16x4(uint16_t* p, f32x4 v, float s) {
-    *(u32x2*)p = (u32x2){pack_bf16x2(v[0] * s, v[1] * s), pack_bf16x2(v[2] * s, v[3] * s)};
-}
 
 // ------------------------------------------------------------------------------------ forward
 template <int NT16>
@@ -312,10 +276,15 @@ inline int set_lds(int bytes) {
         default: { constexpr int NT16 = 20; constexpr int KTW = 3; (void)KTW; __VA_ARGS__; } break; \
     }
 
+int attn_fwd_tiled_launch(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, hipStream_t stream);
+int attn_bwd_tiled_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int N, int H,
+                          float scale, hipStream_t stream);
+
 extern "C" int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
     if (!qkv || !out || !lse || B <= 0 || N <= 0 || H <= 0) return UNITE_EINVAL;
-    const int nt = nt16_for(N);
-    if (!nt) return UNITE_ENOSUP;
+    static const bool force_tiled = getenv("UNITE_ATTN_TILED") && atoi(getenv("UNITE_ATTN_TILED"));
+    const int nt = force_tiled ? 0 : nt16_for(N);
+    if (!nt) return attn_fwd_tiled_launch(qkv, out, lse, B, N, H, scale, (hipStream_t)stream);
     const int64_t bytes = (int64_t)B * N * 3 * H * 64 * 2;
     if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
     const int lds = nt * 16 * 128 * 2;
@@ -332,8 +301,9 @@ extern "C" int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B,
 extern "C" int unite_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
                               int32_t N, int32_t H, float scale, void* stream) {
     if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0) return UNITE_EINVAL;
-    const int nt = nt16_for(N);
-    if (!nt) return UNITE_ENOSUP;
+    static const bool force_tiled = getenv("UNITE_ATTN_TILED") && atoi(getenv("UNITE_ATTN_TILED"));
+    const int nt = force_tiled ? 0 : nt16_for(N);
+    if (!nt) return attn_bwd_tiled_launch(qkv, out, dout, lse, delta, dqkv, B, N, H, scale, (hipStream_t)stream);
     const int64_t bytes = (int64_t)B * N * 3 * H * 64 * 2;
     if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
     const int lds = nt * 16 * 128 * 2;
