@@ -210,6 +210,10 @@ int unite_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp
                      float beta1, float beta2, float eps, int32_t step,
                      const float* grad_scale_dev, const int32_t* found_inf_dev, void* stream);
 
+/* y[m,:] = bf16(row_scale[m / rows_per_scale] * x[m,:])  (f32 [M,D] -> bf16; the GEMM-operand copy of a gradient that did not
+ * come out of a LayerNorm backward, e.g. the token-mean gradient of stage 2). */
+int unite_scale_cast_bf16(const float* x, const float* row_scale, int32_t rows_per_scale, void* y, int32_t M, int32_t D, void* stream);
+
 /* f32 -> bf16 cast of a flat buffer (initial shadow copy of the weights). */
 int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 
@@ -224,6 +228,12 @@ int unite_grad_norm_flat(const float* grad, int64_t n, float max_norm, float* no
  * out[b,:] = mean_n x[b,n,:]  (x f32 [B,N,D], out f32 [B,D]).  Backward: dx[b,n,:] (+)= dout[b,:]/N. */
 int unite_token_mean_fwd(const float* x, float* out, int32_t B, int32_t N, int32_t D, void* stream);
 int unite_token_mean_bwd(const float* dout, float* dx, int32_t accumulate, int32_t B, int32_t N, int32_t D, void* stream);
+
+/* Small fp32 linear layer (classifier head, modeling_finetune.py:313,382; run_stage3.py src_classifier):
+ *   y[b,c] = <x[b,:], W[c,:]> + bias[c];  backward: dx = dy W (optional), dW (+)= dy^T x, db (+)= colsum(dy). */
+int unite_linear_f32_fwd(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t C, int32_t D, void* stream);
+int unite_linear_f32_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db,
+                         int32_t B, int32_t C, int32_t D, int32_t accumulate, void* stream);
 
 /* Softmax cross-entropy with optional per-row weights (run_stage2.py:681, run_stage3.py:486,606-612):
  * loss_sum += sum_i w_i * CE(logits[i,:], label[i]) over rows with label >= 0;  dlogits = scale * w_i *

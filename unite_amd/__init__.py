@@ -10,6 +10,7 @@ All device arithmetic is in unite_amd/lib/libunite_hip.so (C ABI: include/unite_
 """
 from .registry import create_model, register_model, list_models  # noqa: F401
 from . import modeling_adaptation  # noqa: F401  (registers the student factories)
+from . import modeling_finetune  # noqa: F401  (registers the stage-2 classifier factories)
 from . import clip  # noqa: F401
 
 __version__ = "0.1.0"

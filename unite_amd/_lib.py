@@ -65,11 +65,14 @@ SIGNATURES = {
     "unite_decoder_tail_fwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
     "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_adamw_flat": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
+    "unite_scale_cast_bf16": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_cast_f32_bf16": (c_i, [c_p, c_p, c_i64, c_p]),
     "unite_grad_norm_workspace": (c_sz, [c_i64]),
     "unite_grad_norm_flat": (c_i, [c_p, c_i64, c_f, c_p, c_p, c_p, c_p]),
     "unite_token_mean_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_token_mean_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "unite_linear_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_linear_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_softmax_ce": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
 }
 

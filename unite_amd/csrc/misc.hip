@@ -188,6 +188,47 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __rest
     for (int n = 0; n < N; ++n) a += x[((size_t)b * N + n) * D + c];
     out[(size_t)b * D + c] = a / (float)N;
 }
+// ------------------------------------------------------------------------------------ small fp32 linear (classifier head)
+// y[b,c] = <x[b,:], W[c,:]> + bias[c]   -- B <= a few dozen rows, C = number of classes: one workgroup per row
+__global__ __launch_bounds__(256) void linear_f32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int C, int D) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float a = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            const f32x4 xv = *(const f32x4*)(x + (size_t)b * D + d), wv = *(const f32x4*)(W + (size_t)c * D + d);
+            a += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+        a = wave_sum(a);
+        if (lane == 0) y[(size_t)b * C + c] = a + (bias ? bias[c] : 0.f);
+    }
+}
+// dx[b,d] = sum_c dy[b,c] W[c,d]
+__global__ __launch_bounds__(256) void linear_f32_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx, int C,
+                                                            int D) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += dy[(size_t)b * C + c] * W[(size_t)c * D + d];
+        dx[(size_t)b * D + d] = a;
+    }
+}
+// dW[c,d] (+)= sum_b dy[b,c] x[b,d];  db[c] (+)= sum_b dy[b,c]
+__global__ __launch_bounds__(256) void linear_f32_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW,
+                                                            float* __restrict__ db, int B, int C, int D, int accumulate) {
+    const int c = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dy[(size_t)b * C + c] * x[(size_t)b * D + d];
+        dW[(size_t)c * D + d] = accumulate ? dW[(size_t)c * D + d] + a : a;
+    }
+    if (db && threadIdx.x == 0) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dy[(size_t)b * C + c];
+        db[c] = accumulate ? db[c] + a : a;
+    }
+}
+
 __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int accumulate, int N, int D,
                                                              size_t total4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -228,6 +269,17 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
         }
     }
     if (loss_sum && valid && lane == 0) atomicAdd(loss_sum, w * (logf(s) + m - logits[(size_t)row * C + lab]));
+}
+
+// y[m,:] = bf16(row_scale[m / rows_per_scale] * x[m,:])
+__global__ __launch_bounds__(256) void scale_cast_bf16_kernel(const float* __restrict__ x, const float* __restrict__ row_scale, int rows_per_scale,
+                                                              uint16_t* __restrict__ y, int D, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const float sc = row_scale ? row_scale[(e / D) / rows_per_scale] : 1.0f;
+        const f32x4 v = *(const f32x4*)(x + e);
+        *(u32x2*)(y + e) = (u32x2){pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc)};
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
@@ -328,11 +380,44 @@ extern "C" int unite_token_mean_bwd(const float* dout, float* dx, int32_t accumu
     return UNITE_OK;
 }
 
+extern "C" int unite_linear_f32_fwd(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t C, int32_t D, void* stream) {
+    if (!x || !W || !y || B <= 0 || C <= 0 || D <= 0 || (D & 3)) return UNITE_EINVAL;
+    hipLaunchKernelGGL(linear_f32_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, C, D);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_linear_f32_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int32_t B, int32_t C,
+                                    int32_t D, int32_t accumulate, void* stream) {
+    if (!x || !W || !dy || B <= 0 || C <= 0 || D <= 0) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        hipLaunchKernelGGL(linear_f32_dx_kernel, dim3(B), dim3(256), 0, s, dy, W, dx, C, D);
+        UNITE_LAUNCH_CHECK();
+    }
+    if (dW) {
+        hipLaunchKernelGGL(linear_f32_dw_kernel, dim3(C), dim3(256), 0, s, dy, x, dW, db, B, C, D, accumulate);
+        UNITE_LAUNCH_CHECK();
+    }
+    return UNITE_OK;
+}
+
 extern "C" int unite_softmax_ce(const float* logits, const int64_t* labels, const float* row_weight, float grad_scale, float* loss_sum,
                                 float* dlogits, int32_t M, int32_t C, void* stream) {
     if (!logits || !labels || M <= 0 || C <= 0 || C > 1024) return UNITE_EINVAL;
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, labels, row_weight, grad_scale,
                        loss_sum, dlogits, M, C);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_scale_cast_bf16(const float* x, const float* row_scale, int32_t rows_per_scale, void* y, int32_t M, int32_t D,
+                                     void* stream) {
+    if (!x || !y || M <= 0 || D <= 0 || (D & 3) || (row_scale && rows_per_scale <= 0)) return UNITE_EINVAL;
+    const size_t total4 = (size_t)M * D / 4;
+    const size_t blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(scale_cast_bf16_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, x, row_scale,
+                       rows_per_scale, (uint16_t*)y, D, total4);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -262,3 +262,27 @@ def softmax_ce(logits, labels, loss_sum, dlogits=None, row_weight=None, grad_sca
     M, Cc = logits.shape
     _lib.check(lib.unite_softmax_ce(_ptr(logits), _ptr(labels), _ptr(row_weight), grad_scale, _ptr(loss_sum), _ptr(dlogits), M, Cc, _stream()),
                "unite_softmax_ce")
+
+
+def linear_f32_fwd(x, W, bias, y):
+    lib = _lib.load()
+    B, D = x.shape
+    _lib.check(lib.unite_linear_f32_fwd(_ptr(x), _ptr(W), _ptr(bias), _ptr(y), B, W.shape[0], D, _stream()), "unite_linear_f32_fwd")
+    return y
+
+
+def linear_f32_bwd(x, W, dy, dx=None, dW=None, db=None, accumulate: bool = False):
+    lib = _lib.load()
+    B, D = x.shape
+    _lib.check(lib.unite_linear_f32_bwd(_ptr(x), _ptr(W), _ptr(dy), _ptr(dx), _ptr(dW), _ptr(db), B, W.shape[0], D, int(accumulate), _stream()),
+               "unite_linear_f32_bwd")
+
+
+def scale_cast_colsum(x, y_bf16, colsum_out, workspace, row_scale=None, rows_per_scale: int = 1, accumulate: bool = False):
+    """y = bf16(row_scale * x) and colsum_out (+)= column sums of y (the bias gradient of the Linear that consumes y)."""
+    lib = _lib.load()
+    M, D = x.shape
+    _lib.check(lib.unite_scale_cast_bf16(_ptr(x), _ptr(row_scale), rows_per_scale, _ptr(y_bf16), M, D, _stream()), "unite_scale_cast_bf16")
+    if colsum_out is not None:
+        colsum(y_bf16, colsum_out, workspace, accumulate=accumulate)
+    return y_bf16
