@@ -176,6 +176,21 @@ int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t
 int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                          int32_t BT, int32_t N, int32_t n_vis, void* stream);
 
+/* Stage-3 committee masks (src/utils.py:89-120, run_stage3.py:497-500): per frame, member i of k keeps the attention ranks
+ * i, i+k, ... (n_vis of them; the members are disjoint).  mask uint8 [k, BT, N] (1 = masked); vis_tokens int32 [k][BT*n_vis]:
+ * per member, ascending token ids (bt*N + j) inside its own copy of the B target clips (the reference repeats the clips k
+ * times, 'k (B T) N -> (k B) (T N)', and runs one batched pass; the members are independent); vis_rows_cls as above. */
+int unite_greedy_masks(const float* weights, int32_t k, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                       int32_t BT, int32_t N, int32_t n_vis, void* stream);
+
+/* Stage-3 pseudo-label selection (run_stage3.py:488-613) for B target clips with C classes.  strategy: 0 conf, 1 cons,
+ * 2 consORconf, 3 consANDconf, 4 clip_only, 5 clip_matchORconf, 6 oracle.  Outputs: pseudo (int64 [B], the student's
+ * prediction on the full clip), weight (f32 [B] = selected ? (conf_weighted ? max-softmax-prob : 1) : 0), sel / msp optional. */
+int unite_pseudo_label_select(const float* logits_full, const float* logits_masked, int32_t k, const float* clip_probs,
+                              const int64_t* labels_t, int32_t strategy, float threshold, float clip_threshold,
+                              int32_t conf_weighted, int64_t* pseudo, float* weight, uint8_t* sel, float* msp,
+                              int32_t B, int32_t C, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Decoder tail + UMT loss (modeling_adaptation.py:204-207, run_stage1.py:431):
  *   u = LN_eps(y) * gamma + beta ;  o = u / ||u||_2 ;  loss_sum += sum_rows (2 - 2 <o, tgt>)
@@ -203,6 +218,7 @@ int unite_decoder_tail_bwd(const float* y, const float* gamma, const float* beta
  * arrays of n_groups (<= 64) values, passed by value into the launch.  param_bf16 (optional) gets the
  * bf16 shadow copy the GEMMs read.  grad_scale_dev (optional, device f32[1]) multiplies the gradient
  * (1/loss-scale or the clip coefficient); skip the step entirely if *found_inf_dev != 0 (optional).
+ * A group with lr < 0 is left untouched (parameters without a gradient: torch's `p.grad is None`).
  * ------------------------------------------------------------------------------------ */
 int unite_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                      const uint8_t* chunk_group, int64_t n_elems,

@@ -472,3 +472,69 @@ def stage3_target_loss(logits_masked_last: Tensor, sel: Tensor, labels: Tensor, 
     ce = F.cross_entropy(logits_masked_last[sel], labels[sel], reduction="none")
     sel_ratio = sel.float().mean()
     return tgt_ratio * sel_ratio * (msp_t[sel] * ce).mean()
+
+
+def stage3_pseudo_labels(logits_full_t: Tensor, logits_masked_t: Tensor, strategy: str, clip_probs_t: Optional[Tensor] = None,
+                         labels_t: Optional[Tensor] = None, clip_threshold: float = 0.5):
+    """run_stage3.py:488-593, every selection_strategy.  Returns (sel bool (B,), pseudo-label (B,), msp (B,))."""
+    probs = logits_full_t.softmax(dim=-1)
+    msp_t, preds_t = probs.max(dim=-1)
+    cons, conf = stage3_committee_select(logits_full_t, logits_masked_t, 0.5)
+    if strategy == "conf":
+        sel = conf
+    elif strategy == "cons":
+        sel = cons
+    elif strategy == "consORconf":
+        sel = cons | conf                                                 # :533-534
+    elif strategy == "consANDconf":
+        sel = cons & conf                                                 # :535-536
+    elif strategy == "clip_only":
+        clip_msp, _ = clip_probs_t.max(dim=-1)                            # :551-554: CLIP confident at global_threshold (0.5, :522);
+        sel = clip_msp >= 0.5                                             # the label stays the student's prediction (:603)
+    elif strategy == "clip_matchORconf":
+        sel, _, _ = stage3_select(logits_full_t, clip_probs_t, clip_threshold)
+    elif strategy == "oracle":
+        sel = preds_t == labels_t                                         # :585-587
+    else:
+        raise ValueError(strategy)
+    return sel, preds_t, msp_t
+
+
+def stage3_loss(student_sd: SD, teacher_sd: SD, cls_w: Tensor, cls_b: Tensor, videos_s: Tensor, labels_s: Tensor,
+                videos_t: Tensor, videos_t_aug: Tensor, labels_t: Tensor, scfg: StudentCfg, tcfg: TeacherCfg, mask_ratio: float,
+                strategy: str, clip_probs_t: Optional[Tensor] = None, clip_threshold: float = 0.5, src_ratio_pl: float = 1.0,
+                tgt_ratio: float = 1.0, conf_weighted: bool = True, attn: Optional[Tensor] = None):
+    """One stage-3 loss evaluation, run_stage3.py:434-625 (train_masked, k = 2 committee, mean-pooled tokens, linear src_classifier).
+    A composition of pieces that are each pinned on the reference's vectors (student x_vis, teacher attention, greedy masks,
+    selection); the composition itself follows the cited lines.  Returns (loss, loss_s, loss_t, sel)."""
+    B_s, B_t = videos_s.shape[0], videos_t.shape[0]
+    if attn is None:
+        _, attn = teacher_forward(teacher_sd, videos_t_aug, tcfg, return_attn=True)            # :434-451, (B_t*T, N)
+    N_all = scfg.num_patches
+    full = torch.zeros(1, N_all, dtype=torch.bool)
+
+    def classify(x_vis):
+        return F.linear(x_vis.mean(dim=1), cls_w, cls_b)                                       # :333-338, :477
+
+    x_s, _ = student_forward(student_sd, videos_s, full.expand(B_s, -1), scfg, clip_only=False)       # :475
+    logits_s = classify(x_s)
+    with torch.no_grad():
+        x_t, _ = student_forward(student_sd, videos_t, full.expand(B_t, -1), scfg, clip_only=False)   # :480-483
+        logits_full_t = classify(x_t)
+    loss_s = F.cross_entropy(logits_s, labels_s)                                               # :486
+    k = 2
+    masks = get_greedy_masks(attn, mask_ratio, k)                                              # :497, (k, B_t*T, N)
+    logits_masked = []
+    for i in range(k):
+        m = masks[i].reshape(B_t, -1)                                                          # 'k (B T) N -> (k B) (T N)'
+        x_m, _ = student_forward(student_sd, videos_t_aug, m, scfg, clip_only=False)           # :503
+        logits_masked.append(classify(x_m))
+    logits_masked = torch.stack(logits_masked)
+    sel, pseudo, msp = stage3_pseudo_labels(logits_full_t, logits_masked.detach(), strategy, clip_probs_t, labels_t, clip_threshold)
+    if sel.sum() > 0:
+        w = msp if conf_weighted else torch.ones_like(msp)
+        ce = F.cross_entropy(logits_masked[-1][sel], pseudo[sel], reduction="none")
+        loss_t = tgt_ratio * sel.float().mean() * (w[sel] * ce).mean()                         # :599-613
+    else:
+        loss_t = torch.zeros(())
+    return src_ratio_pl * loss_s + loss_t, loss_s, loss_t, sel

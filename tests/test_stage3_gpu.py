@@ -1,0 +1,170 @@
+"""Stage-3 (collaborative self-training, run_stage3.py:333-710) on the MI355X against the CPU oracle (-m gpu).
+The oracle's pieces (student x_vis, teacher CLS attention, greedy masks, selection) are pinned on the reference's golden
+vectors (tests/test_oracle_golden.py); the step here composes them as the cited lines do.
+Tolerances: masks / selection / pseudo-labels bit-exact; 4-clip CE losses absolute 2.5e-2 (logits abs 2e-2); per-tensor gradient relative L2 <= 5e-2;
+the parameter update after one AdamW step: |dp| <= 1.2 lr everywhere and clip_decoder.* untouched."""
+from functools import partial
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import umt_oracle as O  # noqa: E402
+from oracle.filler import fill_state_dict, make_videos  # noqa: E402
+from tests.shapes import student_shapes, teacher_shapes  # noqa: E402
+
+DEV = "cuda"
+S3_T = O.TeacherCfg(input_resolution=64, patch_size=16, width=128, layers=2, heads=2, output_dim=64, clip_return_layers=(1,))
+S3_S = O.StudentCfg(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=2, tubelet_size=1,
+                    clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=(1,))
+NCLS = 5
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def build():
+    from unite_amd.modeling_adaptation import AdaptationVisionTransformer
+    from unite_amd.clip import VisionTransformer
+    s = AdaptationVisionTransformer(img_size=64, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
+                                    mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=2,
+                                    tubelet_size=1, clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=[1])
+    t = VisionTransformer(input_resolution=64, patch_size=16, width=128, layers=2, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[1])
+    return s, t
+
+
+def test_greedy_masks_kernel_vs_oracle():
+    from unite_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for BT, N, ratio, k in ((6, 16, 0.75, 2), (16, 196, 0.8, 2), (4, 196, 0.5, 2), (3, 49, 0.8, 3)):
+        attn = torch.rand(BT, N, generator=g)
+        ref = O.get_greedy_masks(attn, ratio, k)                       # (k, BT, N) True = masked
+        n_vis = N - int(N * ratio)
+        mask = torch.empty(k, BT, N, dtype=torch.uint8, device=DEV)
+        vis = torch.empty(k, BT * n_vis, dtype=torch.int32, device=DEV)
+        ops.greedy_masks(attn.to(DEV), k, mask, vis, n_vis)
+        assert torch.equal(mask.cpu().bool(), ref)
+        for i in range(k):
+            want = (~ref[i]).reshape(-1).nonzero().flatten().to(torch.int32)          # ascending token order (x[~mask])
+            assert torch.equal(vis[i].cpu(), want)
+
+
+def test_pseudo_label_select_kernel_vs_oracle():
+    from unite_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, C, k = 257, 12, 2
+    lf = torch.randn(B, C, generator=g) * 2.5
+    lm = lf[None] + torch.randn(k, B, C, generator=g) * 1.5
+    clip = (torch.randn(B, C, generator=g) * 2.0).softmax(-1)
+    labels = torch.randint(0, C, (B,), generator=g)
+    for strategy in ("conf", "cons", "consORconf", "consANDconf", "clip_only", "clip_matchORconf", "oracle"):
+        for cw in (True, False):
+            sel_r, pl_r, msp_r = O.stage3_pseudo_labels(lf, lm, strategy, clip, labels, clip_threshold=0.4)
+            pseudo = torch.empty(B, dtype=torch.int64, device=DEV)
+            weight = torch.empty(B, dtype=torch.float32, device=DEV)
+            sel = torch.empty(B, dtype=torch.uint8, device=DEV)
+            msp = torch.empty(B, dtype=torch.float32, device=DEV)
+            ops.pseudo_label_select(lf.to(DEV), lm.to(DEV), strategy, 0.5, 0.4, cw, pseudo, weight, clip_probs=clip.to(DEV),
+                                    labels_t=labels.to(DEV), sel=sel, msp=msp)
+            assert torch.equal(sel.cpu().bool(), sel_r), strategy
+            assert torch.equal(pseudo.cpu(), pl_r)
+            torch.testing.assert_close(msp.cpu(), msp_r, atol=1e-5, rtol=1e-5)
+            torch.testing.assert_close(weight.cpu(), torch.where(sel_r, msp_r if cw else torch.ones_like(msp_r), torch.zeros(())), atol=1e-5, rtol=1e-5)
+
+
+def _setup(seed=0):
+    s, t = build()
+    ssd = fill_state_dict(student_shapes(S3_S), 21 + seed)
+    tsd = fill_state_dict(teacher_shapes(S3_T), 22 + seed)
+    s.load_state_dict(ssd)
+    t.load_state_dict(tsd)
+    g = torch.Generator().manual_seed(5 + seed)
+    cls = torch.nn.Linear(128, NCLS)
+    with torch.no_grad():
+        cls.weight.copy_(torch.randn(NCLS, 128, generator=g) * 0.35)
+        cls.bias.copy_(torch.randn(NCLS, generator=g) * 0.1)
+    B = 4
+    data = dict(videos_s=make_videos(B, 2, 64, 64, seed=31 + seed), videos_t=make_videos(B, 2, 64, 64, seed=32 + seed),
+                videos_t_aug=make_videos(B, 2, 64, 64, seed=33 + seed), labels_s=torch.randint(0, NCLS, (B,), generator=g),
+                labels_t=torch.randint(0, NCLS, (B,), generator=g), clip_probs=(torch.randn(B, NCLS, generator=g) * 2).softmax(-1))
+    return s.to(DEV).train(), t.to(DEV).eval(), cls.to(DEV), ssd, tsd, data
+
+
+@pytest.mark.parametrize("strategy", ["clip_matchORconf", "consORconf"])
+def test_stage3_step_vs_oracle(strategy):
+    from unite_amd.engine_stage3 import stage3_step
+    s, t, cls, ssd, tsd, d = _setup(seed=1)
+    # student predictions on the target clips are (2, 3, 3, 2) with msp (.54, .56, .45, .48): CLIP rows = match / unsure /
+    # unsure / confident-other -> clip_matchORconf selects (1, 1, 0, 1); consORconf selects by committee agreement or msp >= .5
+    d["clip_probs"] = torch.tensor([[.1, .1, .6, .1, .1], [.3, .2, .2, .1, .2], [.3, .2, .2, .1, .2], [.9, .025, .025, .025, .025]])
+    args = SimpleNamespace(masking_type="clip_attention", selection_strategy=strategy, clip_threshold=0.5, conf_weighted_loss=True,
+                           class_loss_tgt_ratio=1.0, class_loss_src_ratio_pl=0.7, train_masked=True, full_oracle=False)
+    dd = {k: v.to(DEV) for k, v in d.items()}
+    loss, loss_s, loss_t, sel = stage3_step(s, t, cls, dd["videos_s"], dd["labels_s"], dd["videos_t"], dd["videos_t_aug"], dd["labels_t"],
+                                            args, 0.75, clip_probs_fn=lambda v: dd["clip_probs"])
+    # the oracle evaluates the same step with the masks the HIP teacher produced being re-derived from ITS OWN attention;
+    # attention ranks of near-ties can differ in bf16, so compare the masks first and reuse the oracle's attention only if equal
+    ssd_g = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+    ref_loss, ref_s, ref_t, ref_sel = O.stage3_loss(ssd_g, tsd, cls.weight.detach().cpu(), cls.bias.detach().cpu(), d["videos_s"], d["labels_s"],
+                                                    d["videos_t"], d["videos_t_aug"], d["labels_t"], S3_S, S3_T, 0.75, strategy,
+                                                    d["clip_probs"], clip_threshold=0.5, src_ratio_pl=0.7, tgt_ratio=1.0)
+    _, attn_ref = O.teacher_forward(tsd, d["videos_t_aug"], S3_T, return_attn=True)
+    attn_hip = t.forward_attention(dd["videos_t_aug"]).cpu()
+    torch.testing.assert_close(attn_hip, attn_ref, atol=2e-3, rtol=5e-2)      # 17 keys: values ~0.06-0.2, bf16 q.k
+    if not torch.equal(O.get_greedy_masks(attn_hip, 0.75, 2), O.get_greedy_masks(attn_ref, 0.75, 2)):
+        ref_loss, ref_s, ref_t, ref_sel = O.stage3_loss(ssd_g, tsd, cls.weight.detach().cpu(), cls.bias.detach().cpu(), d["videos_s"],
+                                                        d["labels_s"], d["videos_t"], d["videos_t_aug"], d["labels_t"], S3_S, S3_T, 0.75,
+                                                        strategy, d["clip_probs"], clip_threshold=0.5, src_ratio_pl=0.7, tgt_ratio=1.0,
+                                                        attn=attn_hip)
+    assert torch.equal(sel.cpu().bool(), ref_sel)
+    assert ref_sel.any() and float(ref_t.detach()) > 0, "test data must select something"
+    # x_vis agrees to 0.7 % (bf16 GEMM operands); the test classifier is sharp (|logit| ~ 3), so logits move by <= 2e-2 (the
+    # stage-2 logits tolerance) and a 4-clip CE by at most twice that
+    assert abs(loss_s.item() - ref_s.item()) <= 2.5e-2
+    assert abs(loss_t.item() - ref_t.item()) <= 2.5e-2
+    assert abs(loss.item() - ref_loss.item()) <= 4e-2
+    ref_loss.backward()
+    loss.backward()
+    for k, p in s.named_parameters():
+        if k.startswith("clip_decoder."):
+            assert ssd_g[k].grad is None or ssd_g[k].grad.abs().max() == 0
+            assert p.grad is None or p.grad.abs().max() == 0
+            continue
+        e = rel_l2(p.grad.cpu(), ssd_g[k].grad)
+        assert e <= 5e-2, (k, e)
+
+
+def test_stage3_engine_epoch_updates_encoder_only():
+    from unite_amd.engine_stage3 import train_one_epoch
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount
+    s, t, cls, ssd, tsd, d = _setup(seed=1)
+    args = SimpleNamespace(masking_type="clip_attention", selection_strategy="consORconf", clip_threshold=0.5, conf_weighted_loss=True,
+                           class_loss_tgt_ratio=1.0, class_loss_src_ratio_pl=1.0, class_loss_src_ratio=1e-12, train_masked=True,
+                           full_oracle=False, return_aug_for_val=True, log_freq=1, epochs=1,
+                           opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+    opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+    scaler = NativeScalerWithGradNormCount()
+    src_loader = [(d["videos_s"], d["labels_s"])] * 2
+    tgt_loader = [(d["videos_t"], d["videos_t_aug"], d["labels_t"])]          # shorter than the source loader: it is re-iterated
+    before = {k: v.detach().clone() for k, v in s.state_dict().items()}
+    cls_before = cls.weight.detach().clone()
+    stats = train_one_epoch(s, src_loader, tgt_loader, opt, torch.device(DEV), 0, scaler, max_norm=1.0, src_classifier=cls, teacher_model=t,
+                            mask_ratio=0.75, args=args)
+    assert set(stats) >= {"loss", "loss_class", "loss_class_t", "select_ratio", "grad_norm", "lr"}
+    assert stats["loss"] > 0 and stats["grad_norm"] > 0
+    after = s.state_dict()
+    moved = 0
+    for k in before:
+        delta = (after[k].float() - before[k].float()).abs().max().item()
+        if k.startswith("clip_decoder."):
+            assert delta == 0, k                                   # no gradient -> AdamW skips them (no weight decay either)
+        else:
+            assert delta <= 2 * 1.2e-3 + 2 * 1e-3 * 0.05 * before[k].abs().max().item() + 1e-7, (k, delta)
+            moved += delta > 0
+    assert moved >= len(before) - 4 - 2
+    assert torch.equal(cls.weight.detach(), cls_before)           # A-8: the classifier is used, never optimised

@@ -62,6 +62,8 @@ SIGNATURES = {
     "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_mask_to_tokens": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_greedy_masks": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_pseudo_label_select": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "unite_decoder_tail_fwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p]),
     "unite_decoder_tail_bwd": (c_i, [c_p, c_p, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_adamw_flat": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),

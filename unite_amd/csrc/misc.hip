@@ -137,6 +137,98 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------ stage 3: greedy committee masks
+// utils.get_greedy_masks (reference src/utils.py:89-120): per frame sort the attention descending; committee member i keeps
+// ranks i, i+k, i+2k, ... (its first n_vis of them).  One workgroup per frame, rank by counting (ties: lower index first).
+__global__ __launch_bounds__(256) void greedy_masks_kernel(const float* __restrict__ weights, int k, uint8_t* __restrict__ mask,
+                                                           int32_t* __restrict__ vis_tokens, int32_t* __restrict__ vis_rows_cls, int BT, int N,
+                                                           int n_vis) {
+    __shared__ float key[256];
+    __shared__ int member[256];
+    const int bt = blockIdx.x, j = threadIdx.x;
+    const float w = (j < N) ? weights[(size_t)bt * N + j] : -INFINITY;
+    key[j] = w;
+    __syncthreads();
+    int mem = -1;
+    if (j < N) {
+        int rank = 0;
+        for (int i = 0; i < N; ++i) {
+            const float wi = key[i];
+            rank += (wi > w) || (wi == w && i < j);
+        }
+        if (rank / k < n_vis) mem = rank % k;
+    }
+    member[j] = mem;
+    __syncthreads();
+    if (j < N) {
+        for (int i = 0; i < k; ++i) mask[((size_t)i * BT + bt) * N + j] = (mem == i) ? 0 : 1;
+        if (mem >= 0) {
+            int pos = 0;
+            for (int i = 0; i < j; ++i) pos += (member[i] == mem);
+            const size_t o = ((size_t)mem * BT + bt) * n_vis + pos;
+            vis_tokens[o] = bt * N + j;                       // token id inside this member's own copy of the B target clips
+            if (vis_rows_cls) vis_rows_cls[o] = bt * (N + 1) + 1 + j;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ stage 3: pseudo-label selection
+// run_stage3.py:488-613 on device, one thread per target clip.  weight[b] = sel_b * (conf_weighted ? msp_b : 1), label = student
+// prediction on the full clip; the engine's target loss is then  ratio / B_t * sum_b weight_b * CE(masked logits_b, label_b)
+// (= ratio * sel_ratio * mean over the selected clips, :599-613) with no host sync on the selection count.
+enum { SEL_CONF = 0, SEL_CONS = 1, SEL_CONS_OR_CONF = 2, SEL_CONS_AND_CONF = 3, SEL_CLIP_ONLY = 4, SEL_CLIP_MATCH_OR_CONF = 5, SEL_ORACLE = 6 };
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits_full, const float* __restrict__ logits_masked, int k,
+                                                           const float* __restrict__ clip_probs, const int64_t* __restrict__ labels_t,
+                                                           int strategy, float threshold, float clip_threshold, int conf_weighted,
+                                                           int64_t* __restrict__ pseudo, float* __restrict__ weight, uint8_t* __restrict__ sel_out,
+                                                           float* __restrict__ msp_out, int B, int C) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* lf = logits_full + (size_t)b * C;
+    float m = -INFINITY;
+    int pred = 0;
+    for (int c = 0; c < C; ++c)
+        if (lf[c] > m) { m = lf[c]; pred = c; }
+    float ssum = 0.f;
+    for (int c = 0; c < C; ++c) ssum += __expf(lf[c] - m);
+    const float msp = 1.0f / ssum;                                 // max softmax probability (:489-490)
+    int votes = 0;
+    for (int i = 0; i < k; ++i) {
+        const float* lm = logits_masked + ((size_t)i * B + b) * C;
+        float mm = -INFINITY;
+        int pm = 0;
+        for (int c = 0; c < C; ++c)
+            if (lm[c] > mm) { mm = lm[c]; pm = c; }
+        votes += (pm == pred);
+    }
+    const bool cons = votes >= k;                                  // :510-520
+    const bool conf = msp >= threshold;                            // :522-523 (global_threshold is overwritten to 0.5 by the caller)
+    bool sel = false;
+    if (strategy == SEL_CONF) sel = conf;
+    else if (strategy == SEL_CONS) sel = cons;
+    else if (strategy == SEL_CONS_OR_CONF) sel = cons || conf;
+    else if (strategy == SEL_CONS_AND_CONF) sel = cons && conf;
+    else if (strategy == SEL_ORACLE) sel = labels_t && labels_t[b] == pred;
+    else {
+        float cm = -INFINITY;
+        int cp = 0;
+        for (int c = 0; c < C; ++c) {
+            const float v = clip_probs[(size_t)b * C + c];
+            if (v > cm) { cm = v; cp = c; }
+        }
+        if (strategy == SEL_CLIP_ONLY) sel = cm >= threshold;      // :551-554
+        else {                                                      // clip_matchORconf, :556-572
+            const bool match = cp == pred;
+            const bool sconf = msp >= clip_threshold, cconf = cm >= clip_threshold;
+            sel = match || ((sconf != cconf) && !match);
+        }
+    }
+    pseudo[b] = pred;                                              // :575-576: the student's prediction is the label
+    weight[b] = sel ? (conf_weighted ? msp : 1.0f) : 0.0f;
+    if (sel_out) sel_out[b] = sel ? 1 : 0;
+    if (msp_out) msp_out[b] = msp;
+}
+
 // ------------------------------------------------------------------------------------ CLS-row attention probabilities
 // one workgroup per frame (bt); thread j <-> key j; loops over heads.  qkv packed [B*N, 3*H*64].
 __global__ __launch_bounds__(256) void attn_cls_probs_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ probs, int N, int H,
@@ -353,6 +445,26 @@ extern "C" int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, in
     if (!mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
     hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull,
                        (const int64_t*)nullptr, mask, (uint8_t*)nullptr, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_greedy_masks(const float* weights, int32_t k, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls, int32_t BT,
+                                  int32_t N, int32_t n_vis, void* stream) {
+    if (!weights || !mask || !vis_tokens || k <= 0 || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || (int64_t)n_vis * k > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(greedy_masks_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, k, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_pseudo_label_select(const float* logits_full, const float* logits_masked, int32_t k, const float* clip_probs,
+                                         const int64_t* labels_t, int32_t strategy, float threshold, float clip_threshold,
+                                         int32_t conf_weighted, int64_t* pseudo, float* weight, uint8_t* sel, float* msp, int32_t B, int32_t C,
+                                         void* stream) {
+    if (!logits_full || !logits_masked || !pseudo || !weight || B <= 0 || C <= 0 || k <= 0 || strategy < 0 || strategy > 6) return UNITE_EINVAL;
+    if ((strategy == 4 || strategy == 5) && !clip_probs) return UNITE_EINVAL;
+    hipLaunchKernelGGL(pseudo_label_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits_full, logits_masked, k, clip_probs,
+                       labels_t, strategy, threshold, clip_threshold, conf_weighted, pseudo, weight, sel, msp, B, C);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

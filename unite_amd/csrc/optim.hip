@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ par
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int gidx = chunk_group ? chunk_group[chunk] : 0;
         const float lr = tab.lr[gidx], wd = tab.wd[gidx];
+        if (lr < 0.f) continue;              // group without gradients this step: torch.optim.AdamW's `if p.grad is None: continue`
         const float decay = 1.0f - lr * wd, step = lr * inv_bc1;
         const int64_t i = (chunk << 10) + threadIdx.x * 4;
         if (i + 4 <= n) {

@@ -256,6 +256,56 @@ class _StudentRuntime:
         ops.mask_to_tokens(m8.view(-1), vis, n_vis // T, B * T, N)
         return vis, n_vis
 
+    # -- encoder only (stage 3): x_vis = encoder.norm(blocks(x)) for the listed tokens, in its own activation slot
+    def encode(self, videos, vis_tokens, n_vis, slot: str, training: bool, save: bool = True):
+        """reference modeling_adaptation.py:171-179 with the Identity head: returns x_vis f32 [B*n_vis, D].  vis_tokens = None
+        keeps every token (the 'full_vis_mask' passes of run_stage3.py:468-483)."""
+        fp, r = self.fp, self.runner
+        r.use_slot(slot)
+        ws = self.ws
+        fp.refresh_if_stale()
+        B = videos.shape[0]
+        M, D = B * n_vis, self.D
+        dp = r.drop_path_scales(B, training)
+        x0 = r.embed(videos, vis_tokens, M)
+        xs = r.blocks_forward(x0, B, n_vis, self.depth, dp, save=save)
+        xv = ws.get("enc.xv", (M, D), F32)
+        mean, rstd = ws.get("enc.mean", (M,), F32), ws.get("enc.rstd", (M,), F32)
+        ops.layernorm_fwd(xs[-1], self.norm_w, self.norm_b, self.model.ln_eps, xv, mean=mean, rstd=rstd)
+        self._enc = getattr(self, "_enc", {})
+        self._enc[slot] = dict(B=B, n_vis=n_vis, M=M, dp=dp, x_last=xs[-1], mean=mean, rstd=rstd, saved=save)
+        r.use_slot("")
+        return xv
+
+    def encode_backward(self, dxv, slot: str, notify: bool = True):
+        """gradient of an encode() pass from d(x_vis) (f32 [M, D]); parameter gradients follow fp.accumulate.  notify=False keeps
+        the gradient reducer quiet (a further pass will still add to the same buckets)."""
+        fp, r = self.fp, self.runner
+        c = self._enc[slot]
+        if not c["saved"]:
+            raise RuntimeError("encode(..., save=False) keeps no activations")
+        r.use_slot(slot)
+        ws = self.ws
+        M, D, N = c["M"], self.D, c["n_vis"]
+        acc = fp.accumulate
+        lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, self.C)))
+        last = self.depth - 1
+        dx = ws.get("bw.dxtop", (M, D), F32)
+        dxb = ws.get("bw.dxtopb", (M, D), BF16)
+        ops.layernorm_bwd(dxv, c["x_last"], c["mean"], c["rstd"], self.norm_w, dx_out=dx, dx_bf16=dxb,
+                          row_scale=None if c["dp"] is None else c["dp"][last, 1], rows_per_scale=N,
+                          dgamma=self.g_norm_w, dbeta=self.g_norm_b, dxsum=r._blk[last]["g:mlp.fc2.bias"], accumulate=acc, workspace=lnws)
+        hook = self.layer_done_hook if notify else None
+        if hook is not None:
+            hook("norm")
+        dx0, dx0b = r.blocks_backward(dx, dxb, self.depth, layer_done=hook)
+        r.embed_backward(dx0b)
+        if hook is not None:
+            hook("patch_embed")
+        r.use_slot("")
+        fp.accumulate = True
+        fp.ensure_grad_views()
+
     # -- forward up to the decoder pre-activations
     def forward_features(self, videos, vis_tokens, n_vis, clip_only, training):
         fp, r, ws = self.fp, self.runner, self.ws
@@ -297,7 +347,7 @@ class _StudentRuntime:
         # decoder heads: dgrad -> gradient of the normalised tap (bf16), wgrad/bias into the flat buffer
         for k in range(len(self.taps)):
             d, t = self.dec[k], self._tap[k]
-            dy = ws.bufs[f"dec.dy{k}"]
+            dy = ws.peek(f"dec.dy{k}")
             dxn = ws.get(f"dec.dxn{k}", (M, D), BF16)
             ops.gemm(dy, d["w"], dxn, trans_b=True)
             ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)      # head bias grad: dysum of the tail
@@ -312,7 +362,7 @@ class _StudentRuntime:
             t = self._tap[k]
             out = ws.get(f"bw.dxt{li & 1}", (M, D), F32)
             outb = ws.get("bw.dxtb", (M, D), BF16)
-            ops.layernorm_bwd(ws.bufs[f"dec.dxn{k}"], t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
+            ops.layernorm_bwd(ws.peek(f"dec.dxn{k}"), t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
                               dx_bf16=outb, row_scale=scale, rows_per_scale=N, workspace=lnws,
                               dgamma=self.g_norm_w, dbeta=self.g_norm_b, dxsum=dxsum,
                               # encoder.norm's gamma/beta ADD over the taps (bit 0); the bias column sums follow zero_grad (bit 1)

@@ -286,3 +286,22 @@ def scale_cast_colsum(x, y_bf16, colsum_out, workspace, row_scale=None, rows_per
     if colsum_out is not None:
         colsum(y_bf16, colsum_out, workspace, accumulate=accumulate)
     return y_bf16
+
+
+def greedy_masks(weights, k: int, mask, vis_tokens, n_vis: int, vis_rows_cls=None):
+    lib = _lib.load()
+    BT, N = weights.shape
+    _lib.check(lib.unite_greedy_masks(_ptr(weights), k, _ptr(mask), _ptr(vis_tokens), _ptr(vis_rows_cls), BT, N, n_vis, _stream()),
+               "unite_greedy_masks")
+
+
+SELECTION = {"conf": 0, "cons": 1, "consORconf": 2, "consANDconf": 3, "clip_only": 4, "clip_matchORconf": 5, "oracle": 6}
+
+
+def pseudo_label_select(logits_full, logits_masked, strategy: str, threshold: float, clip_threshold: float, conf_weighted: bool,
+                        pseudo, weight, clip_probs=None, labels_t=None, sel=None, msp=None):
+    lib = _lib.load()
+    k, B, Cc = logits_masked.shape
+    _lib.check(lib.unite_pseudo_label_select(_ptr(logits_full), _ptr(logits_masked), k, _ptr(clip_probs), _ptr(labels_t), SELECTION[strategy],
+                                             threshold, clip_threshold, int(conf_weighted), _ptr(pseudo), _ptr(weight), _ptr(sel), _ptr(msp),
+                                             B, Cc, _stream()), "unite_pseudo_label_select")

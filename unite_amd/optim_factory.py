@@ -86,6 +86,35 @@ class FusedAdamW(torch.optim.Optimizer):
         self._flat = flat
         self._step = 0
         self._ready = False
+        self._unused = ()
+
+    def set_unused(self, prefixes):
+        """parameters (by name prefix) that receive no gradient in this training stage: torch.optim.AdamW skips p.grad is None
+        entirely (no weight decay, no moment update) -- stage 3 never back-propagates through clip_decoder.*"""
+        prefixes = tuple(prefixes)
+        if prefixes != self._unused:
+            self._unused = prefixes
+            if self._ready:
+                self._chunk_group = self._build_chunk_table()
+
+    def _build_chunk_table(self):
+        fp = self._flat
+        name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
+        group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                group_of[name_of[id(p)]] = gi
+        missing = [n for n in fp.names if n not in group_of or n.startswith(self._unused or ("\0",))]
+        if missing:
+            # parameters outside the optimizer (frozen / filtered / without gradient): a group the kernel skips (lr < 0)
+            if len(self.param_groups) >= 64:
+                raise ValueError("no spare group for parameters that are not optimised")
+            self._frozen_group = len(self.param_groups)
+            for n in missing:
+                group_of[n] = self._frozen_group
+        else:
+            self._frozen_group = None
+        return fp.chunk_groups(group_of)
 
     def attach(self, flat: FlatParams):
         self._flat = flat
@@ -94,22 +123,7 @@ class FusedAdamW(torch.optim.Optimizer):
         fp = self._flat
         if fp is None:
             raise RuntimeError("FusedAdamW is not attached to a flat parameter buffer (call model.runtime() first)")
-        name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
-        group_of = {}
-        for gi, g in enumerate(self.param_groups):
-            for p in g["params"]:
-                group_of[name_of[id(p)]] = gi
-        missing = [n for n in fp.names if n not in group_of]
-        if missing:
-            # parameters outside the optimizer (frozen / filtered): give them a zero-lr group
-            if len(self.param_groups) >= 64:
-                raise ValueError("no spare group for parameters that are not optimised")
-            self._frozen_group = len(self.param_groups)
-            for n in missing:
-                group_of[n] = self._frozen_group
-        else:
-            self._frozen_group = None
-        self._chunk_group = fp.chunk_groups(group_of)
+        self._chunk_group = self._build_chunk_table()
         self.exp_avg = torch.zeros_like(fp.param)
         self.exp_avg_sq = torch.zeros_like(fp.param)
         self._ready = True
@@ -123,7 +137,7 @@ class FusedAdamW(torch.optim.Optimizer):
         lrs = [float(g["lr"]) for g in self.param_groups]
         wds = [float(g["weight_decay"]) for g in self.param_groups]
         if self._frozen_group is not None:
-            lrs.append(0.0)
+            lrs.append(-1.0)
             wds.append(0.0)
         b1, b2 = self.param_groups[0]["betas"]
         ops.adamw_flat(fp.param, fp.grad, self.exp_avg, self.exp_avg_sq, fp.shadow, self._chunk_group, lrs, wds,

@@ -30,8 +30,13 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
+        self.prefix = ""          # slot prefix: several forward passes (stage 3) keep separate activations / scratch
+
+    def peek(self, name: str) -> torch.Tensor:
+        return self.bufs[self.prefix + name]
 
     def get(self, name: str, shape, dtype) -> torch.Tensor:
+        name = self.prefix + name
         t = self.bufs.get(name)
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
@@ -40,6 +45,7 @@ class Workspace:
         return t
 
     def bytes_(self, name: str, nbytes: int) -> torch.Tensor:
+        name = self.prefix + name
         t = self.bufs.get(name)
         if t is None or t.numel() < nbytes:
             t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
@@ -59,7 +65,18 @@ class ViTRunner:
         self.dp_rates = list(drop_path_rates)
         self.ws = Workspace(fp.device)
         self.saved: List[dict] = []
+        self._fw: dict = {}
+        self._slots: Dict[str, tuple] = {}
+        self._slot = ""
         self.scale = 64 ** -0.5                 # head_dim ** -0.5 (modeling_finetune.py:86)
+
+    def use_slot(self, slot: str) -> None:
+        """Switch the set of saved activations / scratch buffers (stage 3 runs several forward passes of different
+        shapes before their backward passes; each keeps its own slot)."""
+        self._slots[self._slot] = (self.saved, self._fw)
+        self._slot = slot
+        self.ws.prefix = (slot + ":") if slot else ""
+        self.saved, self._fw = self._slots.get(slot, ([], {}))
 
     # ------------------------------------------------------------------ helpers
     def _p(self, name):
@@ -226,7 +243,7 @@ class ViTRunner:
     def embed_backward(self, dxb: torch.Tensor):
         """patch-embed weight/bias gradients from the bf16 gradient w.r.t. x0 (no input gradient: the clip is data)."""
         ws, fp, D = self.ws, self.fp, self.D
-        cols = ws.bufs["pe.cols"]
+        cols = ws.peek("pe.cols")
         M = cols.shape[0]
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(self.Hd, 3 * D)))
         ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate,
