@@ -137,10 +137,18 @@ int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, in
  *   cols[i, c*P*P + ph*P + pw] = bf16(video[b, c, t, gh*P+ph, gw*P+pw]),  token = token_index ?
  *   token_index[i] : i,  token = ((b*T + t)*GH + gh)*GW + gw.   Only the listed tokens are read
  * (the reference embeds all 1568 and drops 80 % two lines later: modeling_finetune.py:174,
- * modeling_adaptation.py:153).
+ * modeling_adaptation.py:153).  P even (16; 14 for CLIP-L/14, clip.py:263-290).  cols rows are ld_cols
+ * elements apart (ld_cols >= 3*P*P, % 8 == 0); columns [3*P*P, ld_cols) are written as zeros, so
+ * the patch-embed GEMM can run with K padded to a 16-byte multiple (588 -> 592).
  * ------------------------------------------------------------------------------------ */
-int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols,
+int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t ld_cols,
                         int32_t n_rows, int32_t B, int32_t T, int32_t H, int32_t W, int32_t P, void* stream);
+
+/* Bicubic resize of `planes` f32 images H x W -> OH x OW with the semantics of
+ * torch.nn.functional.interpolate(mode='bicubic', align_corners=False) (A = -0.75, clamped taps):
+ * the teacher-input resize of run_stage1.py:362-368 / run_stage3.py:438-445 (224 -> 196 for CLIP-L/14). */
+int unite_resize_bicubic(const float* src, float* dst, int32_t planes, int32_t H, int32_t W,
+                         int32_t OH, int32_t OW, void* stream);
 
 /* out[i,:] = table[(index[i] % modulo), :]   (f32, D % 4 == 0) -- sinusoid position rows of the
  * visible tokens (modeling_adaptation.py:144,153,318-319). */

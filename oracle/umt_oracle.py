@@ -317,11 +317,20 @@ def umt_loss(outputs_clip: Tensor, targets_clip: Tensor) -> Tensor:
     return (2 - 2 * (outputs_clip * targets_clip).sum(dim=-1)).mean()
 
 
+def teacher_resize(videos: Tensor, resolution: int) -> Tensor:
+    """run_stage1.py:362-370: per-plane bicubic resize of the teacher's input when its resolution differs."""
+    B, C, T, H, W = videos.shape
+    if H == resolution:
+        return videos
+    out = F.interpolate(videos.reshape(B, C * T, H, W), size=(resolution, resolution), mode="bicubic", align_corners=False)
+    return out.view(B, C, T, resolution, resolution)
+
+
 def stage1_loss(student_sd: SD, teacher_sd: SD, videos: Tensor, mask: Tensor,
                 scfg: StudentCfg, tcfg: TeacherCfg):
     """teacher -> gather -> student -> loss for an explicit mask (clip_loss_data='mixed')."""
     with torch.no_grad():
-        feats, attn = teacher_forward(teacher_sd, videos, tcfg, return_attn=True)
+        feats, attn = teacher_forward(teacher_sd, teacher_resize(videos, tcfg.input_resolution), tcfg, return_attn=True)
         tgt = gather_targets(feats, mask)
     out = student_forward(student_sd, videos, mask, scfg, clip_only=True)
     return umt_loss(out, tgt), out, tgt, attn

@@ -301,8 +301,9 @@ def test_attention_softmax_spike(ops):
     torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
 
 
-def test_attn_cls_probs(ops):
-    B, N, H = 5, 197, 12
+@pytest.mark.parametrize("N,H", [(197, 12), (257, 16), (577, 4), (5, 2)])
+def test_attn_cls_probs(ops, N, H):
+    B = 5
     qkv = bf(rnd(B * N, 3 * H * 64, seed=9))
     _, _, p = _attn_ref(qkv, B, N, H)
     ref = p.mean(1)[:, 0, 1:]
@@ -324,10 +325,28 @@ def test_im2col_and_gather_rows(ops):
     cg = torch.empty(5, 3 * P * P, dtype=torch.bfloat16, device=DEV)
     ops.im2col_gather(vid.to(DEV), idx.to(DEV), cg, P)
     assert torch.equal(cg.cpu(), ref[idx.long()])
+    # patch 14 (CLIP-L/14): 588-wide rows written into a 592-wide buffer whose pad columns come back as zeros
+    B, T, H, W, P = 2, 2, 28, 42, 14
+    vid = rnd(B, 3, T, H, W, seed=4)
+    ref = bf(O.im2col(vid, P, 1)).reshape(-1, 3 * P * P)
+    cols = torch.full((ref.shape[0], 592), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.im2col_gather(vid.to(DEV), None, cols, P)
+    assert torch.equal(cols[:, :588].cpu(), ref) and (cols[:, 588:] == 0).all()
     table = rnd(36, 128, seed=2)
     out = torch.empty(5, 128, device=DEV)
     ops.gather_rows(table.to(DEV), idx.to(DEV), out, modulo=36)
     assert torch.equal(out.cpu(), table[idx.long() % 36])
+
+
+@pytest.mark.parametrize("H,W,OH,OW", [(224, 224, 196, 196), (32, 48, 28, 28), (20, 20, 33, 47)])
+def test_resize_bicubic_matches_torch_interpolate(ops, H, W, OH, OW):
+    """teacher-input resize (run_stage1.py:362-368): same taps / coefficients as ATen's upsample_bicubic2d; f32 sums of 16
+    products in a different order -> 1e-5 absolute on O(1) pixels."""
+    vid = rnd(2, 3, 3, H, W, seed=H + OW)
+    ref = torch.nn.functional.interpolate(vid.view(2, 9, H, W), size=(OH, OW), mode="bicubic", align_corners=False).view(2, 3, 3, OH, OW)
+    out = torch.empty(2, 3, 3, OH, OW, device=DEV)
+    ops.resize_bicubic(vid.to(DEV), out)
+    torch.testing.assert_close(out.cpu(), ref, atol=1e-5, rtol=1e-5)
 
 
 def test_clip_embed_ln_and_l2(ops):

@@ -65,6 +65,51 @@ def test_teacher_tiny_vs_reference_golden(golden_dir):
     torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=2e-2)
 
 
+def test_teacher_patch14_vs_oracle():
+    """CLIP-L/14 geometry (patch 14: im2col / conv1 rows padded 588 -> 592; 2 x 2 grid here) against the oracle, whose
+    teacher_forward is pinned on the reference's patch-16 vectors above and is patch-size agnostic."""
+    from unite_amd.clip import VisionTransformer
+    cfg = O.TeacherCfg(input_resolution=28, patch_size=14, width=128, layers=2, heads=2, output_dim=64, clip_return_layers=(0, 1))
+    t = VisionTransformer(input_resolution=28, patch_size=14, width=128, layers=2, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[0, 1])
+    sd = fill_state_dict(teacher_shapes(cfg), 77)
+    t.load_state_dict(sd)
+    t = t.to(DEV).eval()
+    vid = make_videos(3, 2, 28, 28, seed=78)
+    feats, attn = t(vid.to(DEV))
+    ref_f, ref_a = O.teacher_forward(sd, vid, cfg, return_attn=True)
+    assert feats.shape == ref_f.shape and attn.shape == ref_a.shape
+    assert cos_min(feats.cpu(), ref_f) >= 0.999
+    torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=5e-2)
+
+
+def test_stage1_step_with_resized_patch14_teacher_vs_oracle():
+    """cfg-5 geometry in miniature: student 32 x 32 @ patch 16, teacher 28 x 28 @ patch 14 (both 2 x 2 grids), clips resized
+    32 -> 28 bicubically for the teacher only (run_stage1.py:362-370)."""
+    from unite_amd.clip import VisionTransformer
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    s, _ = build_tiny()
+    tcfg = O.TeacherCfg(input_resolution=28, patch_size=14, width=128, layers=3, heads=2, output_dim=64, clip_return_layers=(1, 2))
+    t = VisionTransformer(input_resolution=28, patch_size=14, width=128, layers=3, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[1, 2])
+    ssd, tsd = fill_state_dict(student_shapes(TINY_S), 61), fill_state_dict(teacher_shapes(tcfg), 62)
+    s.load_state_dict(ssd)
+    t.load_state_dict(tsd)
+    s, t = s.to(DEV).train(), t.to(DEV).eval()
+    B = 3
+    vid = make_videos(B, 2, 32, 32, seed=63)
+    imp = make_importance(B * 2, 4, seed=64)
+    loss = stage1_step(s, t, vid.to(DEV), B, 0.5, 'attention', None, 'mixed', StepState(), clip_input_resolution=28, importance=imp.to(DEV))
+    mask = O.mask_from_importance(imp, 2, B)
+    ssd_g = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+    ref, _, _, _ = O.stage1_loss(ssd_g, tsd, vid, mask, TINY_S, tcfg)
+    assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item())
+    loss.backward()
+    ref.backward()
+    for k, p in s.named_parameters():
+        assert rel_l2(p.grad.cpu(), ssd_g[k].grad) <= 5e-2, k
+
+
 def test_student_tiny_vs_reference_golden(golden_dir):
     """forward (x_clip, x_vis), loss, every parameter gradient, and 3 AdamW steps -- all against the reference's vectors."""
     from unite_amd.optim_factory import create_optimizer
@@ -206,6 +251,43 @@ def test_stage1_vitb_vs_reference_golden(golden_dir):
             corner = g.reshape(g.shape[0], -1)[:8, :8].cpu()
             ref = torch.from_numpy(z["gcorner." + k])
             assert (corner - ref).norm() <= 0.15 * ref.norm() + 1e-7, k
+
+
+def test_stage1_vitl_cfg5_vs_oracle():
+    """BASELINE config 5 at B = 1: ViT-L/16 student (16 frames -> 640 visible tokens, taps 18..23, decoders 1024 -> 768) with
+    the CLIP-L/14 teacher at 196 x 196 (clips resized 224 -> 196), against the fp32 CPU oracle on the same seeded weights."""
+    import unite_amd
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    taps = [18, 19, 20, 21, 22, 23]
+    scfg = O.StudentCfg(embed_dim=1024, depth=24, num_heads=16, num_frames=16, clip_decoder_embed_dim=1024, clip_output_dim=768,
+                        clip_return_layers=tuple(taps))
+    tcfg = O.TeacherCfg(input_resolution=196, patch_size=14, width=1024, layers=24, heads=16, output_dim=768, clip_return_layers=tuple(taps))
+    student = unite_amd.create_model("adaptation_umt_large_patch16_224", pretrained=False, drop_path_rate=0.0, num_frames=16,
+                                     tubelet_size=1, clip_decoder_embed_dim=1024, clip_output_dim=768, clip_return_layers=taps,
+                                     use_cls_token=False, use_learnable_pos_emb=False, use_checkpoint=False, checkpoint_num=0,
+                                     clip_norm_type='l2', clip_student_return_interval=1, drop_block_rate=None)
+    teacher = unite_amd.clip.clip_l14(pretrained=False, input_resolution=196, return_attn=True, clip_return_layers=taps)
+    ssd, tsd = fill_state_dict(student_shapes(scfg), 91), fill_state_dict(teacher_shapes(tcfg), 92)
+    student.load_state_dict(ssd)
+    teacher.load_state_dict(tsd)
+    student, teacher = student.to(DEV).train(), teacher.to(DEV)
+    B = 1
+    vid = make_videos(B, 16, 224, 224, 93)
+    imp = make_importance(B * 16, 196, 94)
+    loss = stage1_step(student, teacher, vid.to(DEV), B, 0.8, 'attention', None, 'mixed', StepState(), clip_input_resolution=196,
+                       importance=imp.to(DEV))
+    loss.backward()
+    mask = O.mask_from_importance(imp, 40, B)
+    ssd_g = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+    ref, _, _, attn_ref = O.stage1_loss(ssd_g, tsd, vid, mask, scfg, tcfg)
+    ref.backward()
+    torch.testing.assert_close(teacher.runtime().ws.bufs["attn"].cpu(), attn_ref, atol=3e-4, rtol=5e-2)
+    assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item()), (loss.item(), ref.item())
+    gn_ref = torch.sqrt(sum((v.grad ** 2).sum() for v in ssd_g.values() if v.grad is not None)).item()
+    gn = student.runtime().fp.grad.norm().item()
+    assert abs(gn - gn_ref) <= 2e-2 * gn_ref, (gn, gn_ref)
+    worst = max(rel_l2(p.grad.cpu(), ssd_g[k].grad) for k, p in student.named_parameters())
+    assert worst <= 8e-2, worst          # 24 layers of bf16 operands; the per-tensor bound for ViT-B's 12 is 5e-2
 
 
 def test_train_one_epoch_synthetic():

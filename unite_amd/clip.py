@@ -8,8 +8,8 @@ The nn modules only hold parameters; the forward is a fixed launch schedule over
   ln_post + proj + L2-norm on the VISIBLE tokens only (the reference computes the tail for all 1568, clip.py:168-173).
 The last block's head-averaged attention map (clip.py:95-96) is never materialised: only its CLS row is computed.
 
-Built for patch_size 16 / head_dim 64 (clip_b16).  clip_l14 (patch 14: 588-wide im2col rows are not 16-byte
-multiples) is declared but raises NotImplementedError until its padded patch-embed lands.
+Built for head_dim 64: clip_b16 (patch 16) and clip_l14 (patch 14: the 588-wide im2col rows and conv1 rows are zero-padded
+to K = 592 so they stay 16-byte multiples).  Frames of up to 256 patches (+CLS): 224 @ 16, 196 @ 14 (SURVEY 8d cfg 4/5).
 """
 from __future__ import annotations
 
@@ -120,8 +120,8 @@ class VisionTransformer(nn.Module):
 
 class _TeacherRuntime:
     def __init__(self, model: VisionTransformer, dev):
-        if model.patch_size % 4 or (3 * model.patch_size ** 2) % 8:
-            raise NotImplementedError("patch sizes whose im2col rows are not 16-byte multiples (CLIP-L/14) are not built yet")
+        if model.patch_size % 2:
+            raise NotImplementedError("odd patch sizes are not built")
         if model.width != model.heads * 64:
             raise NotImplementedError("head_dim must be 64")
         self.model, self.dev = model, dev
@@ -174,10 +174,19 @@ class _TeacherRuntime:
         BT = B * T
         Mp, Mt = BT * HW, BT * L
         Kpe = 3 * self.P * self.P
-        cols = ws.get("cols", (Mp, Kpe), BF16)
+        Kp = (Kpe + 7) // 8 * 8                       # 588 -> 592 for patch 14: rows stay 16-byte multiples, the pad is zeros
+        cols = ws.get("cols", (Mp, Kp), BF16)
         ops.im2col_gather(videos.contiguous(), None, cols, self.P)
+        conv_w = self.conv_w.view(D, Kpe)
+        if Kp != Kpe:
+            wpad = ws.bufs.get(ws.prefix + "conv_w.pad")
+            if wpad is None:
+                wpad = ws.get("conv_w.pad", (D, Kp), BF16)
+                wpad.zero_()
+            wpad[:, :Kpe].copy_(conv_w)               # 1.2 MB; follows a reloaded state_dict
+            conv_w = wpad
         patches = ws.get("patches", (Mp, D), BF16)
-        ops.gemm(cols, self.conv_w.view(D, Kpe), patches)
+        ops.gemm(cols, conv_w, patches)
         x = ws.get("x.a", (Mt, D), F32)
         ops.clip_embed_ln(patches, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.eps, x, BT, HW, D)
         h = ws.get("h", (Mt, D), BF16)

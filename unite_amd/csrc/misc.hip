@@ -4,9 +4,13 @@
 namespace {
 
 // ------------------------------------------------------------------------------------ im2col of the listed tokens
-// One wavefront per patch row of 3*P*P elements; each lane moves float4 pieces (4 pixels of one 64-B patch line).
+// One wavefront per patch row of 3*P*P elements; each lane moves VEC pixels of one patch line (VEC = 4 for P % 4 == 0: a 64-B
+// line of a 16-pixel patch is 4 lanes; VEC = 2 for P = 14).  Rows are ld_cols wide; columns [3*P*P, ld_cols) are written as zeros
+// so the GEMM's K can be padded to a 16-byte multiple (588 -> 592 for CLIP-L/14).
+template <int VEC>
 __global__ __launch_bounds__(256) void im2col_gather_kernel(const float* __restrict__ video, const int32_t* __restrict__ token_index,
-                                                            uint16_t* __restrict__ cols, int n_rows, int B, int T, int H, int W, int P) {
+                                                            uint16_t* __restrict__ cols, int n_rows, int B, int T, int H, int W, int P,
+                                                            int ld_cols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -15,11 +19,22 @@ __global__ __launch_bounds__(256) void im2col_gather_kernel(const float* __restr
     const int gw = tok % GW, gh = (tok / GW) % GH, t = (tok / (GW * GH)) % T, b = tok / (GW * GH * T);
     const int PP = P * P, KD = 3 * PP;
     const size_t plane = (size_t)H * W;
-    for (int e = lane * 4; e < KD; e += 256) {
-        const int c = e / PP, ph = (e % PP) / P, pw = e % P;
-        const float* src = video + (((size_t)b * 3 + c) * T + t) * plane + (size_t)(gh * P + ph) * W + gw * P + pw;
-        const f32x4 v = *(const f32x4*)src;
-        *(u32x2*)(cols + (size_t)row * KD + e) = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    uint16_t* dst = cols + (size_t)row * ld_cols;
+    for (int e = lane * VEC; e < ld_cols; e += 64 * VEC) {
+        if (e < KD) {
+            const int c = e / PP, ph = (e % PP) / P, pw = e % P;
+            const float* src = video + (((size_t)b * 3 + c) * T + t) * plane + (size_t)(gh * P + ph) * W + gw * P + pw;
+            if (VEC == 4) {
+                const f32x4 v = *(const f32x4*)src;
+                *(u32x2*)(dst + e) = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            } else {
+                const f32x2 v = *(const f32x2*)src;
+                *(uint32_t*)(dst + e) = pack_bf16x2(v[0], v[1]);
+            }
+        } else {
+            if (VEC == 4) *(u32x2*)(dst + e) = (u32x2){0u, 0u};
+            else *(uint32_t*)(dst + e) = 0u;
+        }
     }
 }
 
@@ -231,45 +246,99 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------ CLS-row attention probabilities
 // one workgroup per frame (bt); thread j <-> key j; loops over heads.  qkv packed [B*N, 3*H*64].
+constexpr int CLS_KPT = 4;      // keys per thread: N <= 1024 (257 = 224 @ patch 14 + CLS, 577 = 336 @ 14)
 __global__ __launch_bounds__(256) void attn_cls_probs_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ probs, int N, int H,
                                                              float scale) {
     __shared__ float q[64];
     __shared__ float red[4];
-    const int bt = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = 3 * H * 64;
-    float accp = 0.f;
+    float accp[CLS_KPT] = {0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
         __syncthreads();
-        if (j < 64) q[j] = bf16_to_f32(qkv[(size_t)bt * N * ld + h * 64 + j]) * scale;
+        if (tid < 64) q[tid] = bf16_to_f32(qkv[(size_t)bt * N * ld + h * 64 + tid]) * scale;
         __syncthreads();
-        float s = -INFINITY;
-        if (j < N) {
-            const uint16_t* kp = qkv + ((size_t)bt * N + j) * ld + H * 64 + h * 64;
-            float d = 0.f;
+        float s[CLS_KPT];
+        float m = -INFINITY;
 #pragma unroll
-            for (int c = 0; c < 64; c += 8) {
-                const u32x4 w = *(const u32x4*)(kp + c);
+        for (int i = 0; i < CLS_KPT; ++i) {
+            const int j = tid + 256 * i;
+            s[i] = -INFINITY;
+            if (j < N) {
+                const uint16_t* kp = qkv + ((size_t)bt * N + j) * ld + H * 64 + h * 64;
+                float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    d += q[c + 2 * e] * __uint_as_float(w[e] << 16);
-                    d += q[c + 2 * e + 1] * __uint_as_float(w[e] & 0xFFFF0000u);
+                for (int c = 0; c < 64; c += 8) {
+                    const u32x4 w = *(const u32x4*)(kp + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d += q[c + 2 * e] * __uint_as_float(w[e] << 16);
+                        d += q[c + 2 * e + 1] * __uint_as_float(w[e] & 0xFFFF0000u);
+                    }
                 }
+                s[i] = d;
             }
-            s = d;
+            m = fmaxf(m, s[i]);
         }
-        float m = wave_max(s);
+        m = wave_max(m);
         if (lane == 0) red[wave] = m;
         __syncthreads();
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         __syncthreads();
-        const float e = (j < N) ? __expf(s - m) : 0.f;
-        float t = wave_sum(e);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < CLS_KPT; ++i) {
+            s[i] = (tid + 256 * i < N) ? __expf(s[i] - m) : 0.f;
+            t += s[i];
+        }
+        t = wave_sum(t);
         if (lane == 0) red[wave] = t;
         __syncthreads();
         t = red[0] + red[1] + red[2] + red[3];
-        accp += e / t;
+#pragma unroll
+        for (int i = 0; i < CLS_KPT; ++i) accp[i] += s[i] / t;
     }
-    if (j >= 1 && j < N) probs[(size_t)bt * (N - 1) + (j - 1)] = accp / (float)H;
+#pragma unroll
+    for (int i = 0; i < CLS_KPT; ++i) {
+        const int j = tid + 256 * i;
+        if (j >= 1 && j < N) probs[(size_t)bt * (N - 1) + (j - 1)] = accp[i] / (float)H;
+    }
+}
+
+// ------------------------------------------------------------------------------------ bicubic plane resize (teacher input)
+// torch.nn.functional.interpolate(mode='bicubic', align_corners=False) semantics: source x = (ox + 0.5) * W/OW - 0.5, the four
+// taps floor(x)-1 .. floor(x)+2 clamped to the plane, Keys cubic with A = -0.75, f32 arithmetic.  One thread per output pixel;
+// a wave covers 64 consecutive pixels of a row, so the four source rows are read as contiguous spans.
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void resize_bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int OH,
+                                                             int OW, float sh, float sw) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const float* sp = src + (size_t)blockIdx.z * H * W;
+    const float ry = sh * ((float)oy + 0.5f) - 0.5f, rx = sw * ((float)ox + 0.5f) - 0.5f;
+    const float fy = floorf(ry), fx = floorf(rx);
+    float cy[4], cx[4];
+    cubic_coeffs(ry - fy, cy);
+    cubic_coeffs(rx - fx, cx);
+    const int iy = (int)fy, ix = (int)fx;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int y = min(max(iy - 1 + a, 0), H - 1);
+        float r = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r += cx[b] * sp[(size_t)y * W + min(max(ix - 1 + b, 0), W - 1)];
+        acc += cy[a] * r;
+    }
+    dst[((size_t)blockIdx.z * OH + oy) * OW + ox] = acc;
 }
 
 // ------------------------------------------------------------------------------------ token mean
@@ -388,11 +457,17 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t n_rows, int32_t B, int32_t T,
-                                   int32_t H, int32_t W, int32_t P, void* stream) {
-    if (!video || !cols || n_rows <= 0 || P <= 0 || (P & 3) || H % P || W % P || (W & 3)) return UNITE_EINVAL;
-    hipLaunchKernelGGL(im2col_gather_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, video, token_index,
-                       (uint16_t*)cols, n_rows, B, T, H, W, P);
+extern "C" int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t ld_cols, int32_t n_rows, int32_t B,
+                                   int32_t T, int32_t H, int32_t W, int32_t P, void* stream) {
+    if (!video || !cols || n_rows <= 0 || P <= 0 || (P & 1) || H % P || W % P || (W & 1) || ld_cols < 3 * P * P || (ld_cols & 7))
+        return UNITE_EINVAL;
+    const dim3 grid((n_rows + 3) / 4), block(256);
+    if ((P & 3) == 0 && (W & 3) == 0)
+        hipLaunchKernelGGL(im2col_gather_kernel<4>, grid, block, 0, (hipStream_t)stream, video, token_index, (uint16_t*)cols, n_rows, B, T, H,
+                           W, P, ld_cols);
+    else
+        hipLaunchKernelGGL(im2col_gather_kernel<2>, grid, block, 0, (hipStream_t)stream, video, token_index, (uint16_t*)cols, n_rows, B, T, H,
+                           W, P, ld_cols);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
@@ -470,8 +545,17 @@ extern "C" int unite_pseudo_label_select(const float* logits_full, const float* 
 }
 
 extern "C" int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
-    if (!qkv || !probs || B <= 0 || N <= 1 || N > 256 || H <= 0) return UNITE_EINVAL;
+    if (!qkv || !probs || B <= 0 || N <= 1 || N > 256 * CLS_KPT || H <= 0) return UNITE_EINVAL;
     hipLaunchKernelGGL(attn_cls_probs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, probs, N, H, scale);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_resize_bicubic(const float* src, float* dst, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                                    void* stream) {
+    if (!src || !dst || planes <= 0 || planes > 65535 || H <= 0 || W <= 0 || OH <= 0 || OH > 65535 || OW <= 0) return UNITE_EINVAL;
+    hipLaunchKernelGGL(resize_bicubic_kernel, dim3((OW + 255) / 256, OH, planes), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

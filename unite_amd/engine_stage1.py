@@ -34,6 +34,17 @@ class StepState:
         self.seed = 0
 
 
+def teacher_input(teacher_model, videos, clip_input_resolution):
+    """run_stage1.py:362-370 / run_stage3.py:438-447: bicubic resize of every frame plane when the teacher's resolution differs
+    (224 -> 196 for CLIP-L/14 so that its 14 x 14 grid matches the student's)."""
+    B, C, T, H, W = videos.shape
+    if H == clip_input_resolution:
+        return videos
+    rt = getattr(teacher_model, "module", teacher_model).runtime()
+    out = rt.ws.get("resized", (B, C, T, clip_input_resolution, clip_input_resolution), torch.float32)
+    return ops.resize_bicubic(videos.contiguous(), out)
+
+
 def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state: StepState,
                 clip_input_resolution=224, importance=None):
     """teacher -> mask -> targets -> student loss (device tensors only).  Returns the 0-dim loss tensor (with grad_fn)."""
@@ -41,11 +52,7 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
     rt = student.runtime()
     dev = videos.device
     B, C, T, H, W = videos.shape
-    if H != clip_input_resolution:
-        # run_stage1.py:363-369; a bicubic resize kernel is not part of libunite_hip yet -> this configuration
-        # (CLIP-L/14 teachers) is outside the built path
-        raise NotImplementedError("teacher input resolution != student resolution is not built yet")
-    attn = teacher_model.forward_attention(videos)               # (B*T, N) f32
+    attn = teacher_model.forward_attention(teacher_input(teacher_model, videos, clip_input_resolution))     # (B*T, N) f32
     BT, N = attn.shape
     n_vis_frame = N - int(N * mask_ratio)                        # :380
     n_vis = n_vis_frame * (BT // B)

@@ -25,6 +25,7 @@ from typing import Callable, Iterable, Optional
 import torch
 
 from . import ops, utils
+from .engine_stage1 import teacher_input
 
 F32 = torch.float32
 
@@ -60,7 +61,7 @@ class _Stage3LossFn(torch.autograd.Function):
 
         # masks for the committee from the teacher's CLS attention on the augmented target clips
         if cfg["masking_type"] == "clip_attention":
-            attn_t = teacher_model.forward_attention(videos_t_aug)                     # (B_t*T, N)
+            attn_t = teacher_model.forward_attention(teacher_input(teacher_model, videos_t_aug, cfg["clip_input_resolution"]))   # (B_t*T, N)
         elif cfg["masking_type"] == "random":
             attn_t = torch.rand(B_t * T, N, device=dev)                               # run_stage3.py:455
         else:
@@ -131,9 +132,10 @@ class _Stage3LossFn(torch.autograd.Function):
 
 
 def stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t, args, mask_ratio,
-                clip_probs_fn: Optional[Callable] = None):
+                clip_probs_fn: Optional[Callable] = None, clip_input_resolution: Optional[int] = None):
     student = getattr(model, "module", model)
-    cfg = dict(masking_type=getattr(args, "masking_type", "clip_attention"), mask_ratio=mask_ratio,
+    cfg = dict(clip_input_resolution=clip_input_resolution or videos_t_aug.shape[-1],
+               masking_type=getattr(args, "masking_type", "clip_attention"), mask_ratio=mask_ratio,
                selection_strategy=getattr(args, "selection_strategy", "clip_matchORconf"), clip_threshold=float(getattr(args, "clip_threshold", 0.5)),
                conf_weighted_loss=bool(getattr(args, "conf_weighted_loss", True)), class_loss_tgt_ratio=float(getattr(args, "class_loss_tgt_ratio", 1.0)),
                class_loss_src_ratio_pl=float(getattr(args, "class_loss_src_ratio_pl", 1.0)), train_masked=bool(getattr(args, "train_masked", True)),
@@ -203,7 +205,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
         labels_s, labels_t = labels_s.to(device, non_blocking=True), labels_t.to(device, non_blocking=True)
 
         loss, loss_s, loss_t, sel = stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t,
-                                                args, mask_ratio, clip_probs_fn)
+                                                args, mask_ratio, clip_probs_fn, clip_input_resolution)
         optimizer.zero_grad()
         grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
         pending.append((loss, loss_s, loss_t, sel.float().mean(), grad_norm))

@@ -152,9 +152,25 @@ def im2col_gather(video, token_index, cols, P: int):
     assert video.is_contiguous()
     B, Cc, T, H, W = video.shape
     assert Cc == 3
-    _lib.check(lib.unite_im2col_gather(_ptr(video), _ptr(token_index), _ptr(cols), cols.shape[0], B, T, H, W, P, _stream()),
+    _lib.check(lib.unite_im2col_gather(_ptr(video), _ptr(token_index), _ptr(cols), cols.stride(0), cols.shape[0], B, T, H, W, P, _stream()),
                "unite_im2col_gather")
     return cols
+
+
+def resize_bicubic(video, out):
+    """(B,C,T,H,W) f32 -> out (B,C,T,OH,OW): per-plane bicubic resize, align_corners=False."""
+    lib = _lib.load()
+    _req(video, F32, "video")
+    _req(out, F32, "out")
+    assert video.is_contiguous() and out.is_contiguous() and video.shape[:-2] == out.shape[:-2]
+    H, W = video.shape[-2:]
+    OH, OW = out.shape[-2:]
+    planes = video.numel() // (H * W)
+    for lo in range(0, planes, 32768):                          # grid.z limit
+        n = min(32768, planes - lo)
+        _lib.check(lib.unite_resize_bicubic(video.data_ptr() + lo * H * W * 4, out.data_ptr() + lo * OH * OW * 4, n, H, W, OH, OW, _stream()),
+                   "unite_resize_bicubic")
+    return out
 
 
 def gather_rows(table, index, out, modulo: int = 0):
