@@ -44,13 +44,26 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf to ~1.2e-7 absolute (Abramowitz & Stegun 7.1.26 refined: W. J. Cody-style rational is overkill for values that are
+// rounded to bf16 next): erf(|x|) = 1 - t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-x^2), t = 1 / (1 + p |x|).
+// Two transcendental issues (v_rcp_f32, v_exp_f32) + 8 plain VALU instead of ocml erff's ~30-instruction branchy polynomial:
+// the GEMM epilogues that apply it are VALU-bound (64 lanes / clk / CU against 65536 outputs per 256 x 256 tile).
+__device__ __forceinline__ float fast_exp_neg_sq(float x) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x); }
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float y = 1.0f - poly * fast_exp_neg_sq(ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
     return cdf + x * pdf;
 }
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) with v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions)
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
 
 // 16x16x32 bf16 MFMA: A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], C[row 4(l>>4)+r][col l&15]
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {

@@ -470,7 +470,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         return;
     }
 
-    // ---- epilogue: HALF rows x TILE columns at a time through an unpadded f32 image in the (now idle) ring: two passes,
+    // ---- epilogue: HALF rows x TILE columns at a time through an unpadded f32 image in the (now idle) ring (row stride = 0 mod 64
+    // banks: 16-column groups are XOR-swizzled by the row's lane-group index so the four groups of a ds_write hit 64 banks): two passes,
     // two barriers each, TILE/32 independent 8-column chunks per thread -> wide (16 B / 32 B per lane) coalesced stores.
     float* cs = (float*)smem;
     const int G = lane >> 4, c16 = lane & 15;
@@ -486,14 +487,14 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        cs[(arow + i * 16 + 4 * G + r) * TILE + nh * HALF + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
+                        cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
         __syncthreads();
 #pragma unroll 2
         for (int e = 0; e < TILE / 32; ++e) {
             const int lr = (tid + e * 4 * HALF) / CPR;
             const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
-            if (gm < g.M && gn < g.N)
-                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * TILE + ccol), *(const f32x4*)(cs + lr * TILE + ccol + 4), bias0, bias1);
+            const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
+            if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
         }
         __syncthreads();
     }
@@ -688,14 +689,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        cs[(arow + i * 16 + 4 * G + r) * TN + nh * 128 + bcol + j * 16 + c16] = acc[h][i][nh][j][r];
+                        cs[(arow + i * 16 + 4 * G + r) * TN + ((nh * 128 + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
         __syncthreads();
 #pragma unroll 2
         for (int e = 0; e < 8; ++e) {
             const int lr = (tid >> 5) + e * 8;
             const int gm = m0 + h * 64 + lr, gn = n0 + ccol;
-            if (gm < g.M && gn < g.N)
-                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * TN + ccol), *(const f32x4*)(cs + lr * TN + ccol + 4), bias0, bias1);
+            const float* cp = cs + lr * TN + (ccol ^ (((lr >> 2) & 3) << 4));
+            if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
         }
         __syncthreads();
     }
