@@ -74,6 +74,12 @@ typedef struct unite_gemm_args {
 
 int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
 
+/* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
+ * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117
+ * under autograd) fill the chip together instead of each needing split-K slabs.  Results are identical to `count`
+ * single calls without a workspace (same tile kernel, same accumulation order). */
+int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t count, void* stream);
+
 /* Diagnostics for bench.py's roofline leg: when enabled, every unite_gemm_bf16 launch is bracketed by two HIP events
  * recorded on the launch stream (pool of max_launches pairs; launches beyond the pool are not timed).
  * unite_prof_summary synchronises on the recorded events and returns the summed durations (ms), the number of timed

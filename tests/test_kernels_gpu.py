@@ -68,6 +68,27 @@ def test_gemm_256_tile_exact_integers(ops, ta, tb, M, N, K):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("ta,tb", [(True, True), (False, False)])
+def test_gemm_grouped_matches_single_launches(ops, ta, tb):
+    """unite_gemm_bf16_grouped: four problems of different shapes (the weight gradients of a block) in one launch are
+    bit-identical to four single launches of the same tile kernel (integer data: also equal to the exact product)."""
+    shapes = [(384, 136, 520), (136, 384, 520), (264, 128, 328), (128, 128, 72)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        g = torch.Generator().manual_seed(100 + i)
+        a = torch.randint(-4, 5, (M, K), generator=g).float()
+        b = torch.randint(-4, 5, (N, K), generator=g).float()
+        prev = torch.randint(-8, 9, (M, N), generator=g).float()
+        refs.append(a @ b.t() + (prev if i % 2 else 0))
+        a_d = bf(a.t().contiguous() if ta else a).to(DEV)
+        b_d = bf(b.t().contiguous() if tb else b).to(DEV)
+        out = prev.clone().to(DEV)
+        probs.append((a_d, b_d, out, dict(trans_a=ta, trans_b=tb, accumulate=bool(i % 2))))
+    ops.gemm_grouped(probs)
+    for (a_d, b_d, out, kw), ref in zip(probs, refs):
+        assert torch.equal(out.cpu(), ref)
+
+
 @pytest.mark.parametrize("M,N,K", [(768, 768, 10240), (3072, 768, 2560), (136, 264, 1100)])
 def test_gemm_splitk_weight_gradient(ops, M, N, K):
     """TN product with a workspace: split-K through f32 slabs, fixed summation order (bit-reproducible), exact on integers."""

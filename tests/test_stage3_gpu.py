@@ -154,7 +154,7 @@ def test_stage3_engine_epoch_updates_encoder_only():
     before = {k: v.detach().clone() for k, v in s.state_dict().items()}
     cls_before = cls.weight.detach().clone()
     stats = train_one_epoch(s, src_loader, tgt_loader, opt, torch.device(DEV), 0, scaler, max_norm=1.0, src_classifier=cls, teacher_model=t,
-                            mask_ratio=0.75, args=args)
+                            mask_ratio=0.75, args=args, clip_input_resolution=64)
     assert set(stats) >= {"loss", "loss_class", "loss_class_t", "select_ratio", "grad_norm", "lr"}
     assert stats["loss"] > 0 and stats["grad_norm"] > 0
     after = s.state_dict()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "unite_abi_version": (c_i, []),
     "unite_target_arch": (C.c_char_p, []),
     "unite_gemm_bf16": (c_i, [C.POINTER(GemmArgs), c_p]),
+    "unite_gemm_bf16_grouped": (c_i, [C.POINTER(GemmArgs), c_i, c_p]),
     "unite_prof_enable": (c_i, [c_i, c_i]),
     "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),

@@ -29,9 +29,16 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
 constexpr int CS_LD = 132;                       // f32 row stride of the epilogue image (conflict-free writes)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 64 KiB  (epilogue image: 64 x 132 x 4 = 33 KiB, reuses it)
 
+constexpr int MAX_GROUP = 4;
 struct Params {
-    unite_gemm_args a;
+    unite_gemm_args a;            // the problem (group 0 of a grouped launch)
     uint32_t a_bytes, b_bytes;
+    // grouped launch (unite_gemm_bf16_grouped, deep 128^2 kernel only): problems 1..ngroups-1 and the running tile counts;
+    // workgroup `lin` (after the XCD remap) works on problem gi with tile_end[gi-1] <= lin < tile_end[gi]
+    unite_gemm_args more[MAX_GROUP - 1];
+    uint32_t more_a_bytes[MAX_GROUP - 1], more_b_bytes[MAX_GROUP - 1];
+    int32_t tile_end[MAX_GROUP];
+    int32_t ngroups;
     int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
     float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
     int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
@@ -85,8 +92,8 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 // Epilogue for 8 consecutive output columns of one row (f32 accumulators v0|v1): see unite_hip.h for the order of operations.
 // The bias chunk (b0|b1) is loaded by the caller ONCE per tile, ahead of the stores: vmcnt retires in issue order, so a
 // load issued between the stores of two passes could only be waited for together with every store before it.
-__device__ __forceinline__ void epilogue_chunk(const Params& p, int slice, int gm, int gn, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
-    const unite_gemm_args& g = p.a;
+__device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm_args& g, int slice, int gm, int gn, f32x4 v0, f32x4 v1,
+                                               f32x4 b0, f32x4 b1) {
     if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
         float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
         *(f32x4*)sp = v0;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
             const int col = (tid & 15) * 8;
             const int gm = m0 + half * 64 + lr, gn = n0 + col;
             if (gm < g.M && gn < g.N)
-                epilogue_chunk(p, slice, gm, gn, *(const f32x4*)(cs + lr * CS_LD + col), *(const f32x4*)(cs + lr * CS_LD + col + 4), bias0, bias1);
+                epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)(cs + lr * CS_LD + col), *(const f32x4*)(cs + lr * CS_LD + col + 4), bias0, bias1);
         }
         __syncthreads();
     }
@@ -334,21 +341,44 @@ template <int HALF, bool TA, bool TB>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32;
-    const unite_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int nbn = (g.N + TILE - 1) / TILE, nbm = (g.M + TILE - 1) / TILE, nb = nbm * nbn, nbt = nb * p.splitk;
+    // XCD-aware bijective remap of the launch order, then (grouped launches) the problem this workgroup belongs to
+    const int nbt = (int)gridDim.x;
     const int bid = blockIdx.x, xcd = bid & 7, qq = nbt >> 3, rr = nbt & 7;
     const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int tile = lin % nb, slice = lin / nb;
+    int gi = 0;
+    if (p.ngroups > 1) {
+#pragma unroll
+        for (int i = 0; i < MAX_GROUP - 1; ++i) gi += (i + 1 < p.ngroups && lin >= p.tile_end[i]) ? 1 : 0;
+    }
+    // field-by-field scalar selects with CONSTANT indices: a runtime-indexed address into the by-value kernel argument would
+    // make hipcc copy all of Params to scratch memory (162 scratch instructions, 2 x slower kernels)
+    unite_gemm_args g = p.a;
+    uint32_t a_bytes = p.a_bytes, b_bytes = p.b_bytes;
+    int lin0 = 0;
+    if (p.ngroups > 1) {
+#define UNITE_SEL(f) g.f = gi == 1 ? p.more[0].f : gi == 2 ? p.more[1].f : gi == 3 ? p.more[2].f : g.f
+        UNITE_SEL(M); UNITE_SEL(N); UNITE_SEL(K); UNITE_SEL(A); UNITE_SEL(lda); UNITE_SEL(B); UNITE_SEL(ldb); UNITE_SEL(bias);
+        UNITE_SEL(act); UNITE_SEL(aux_in); UNITE_SEL(ld_aux_in); UNITE_SEL(aux_out); UNITE_SEL(ld_aux_out); UNITE_SEL(row_scale);
+        UNITE_SEL(rows_per_scale); UNITE_SEL(residual); UNITE_SEL(ldr); UNITE_SEL(out); UNITE_SEL(ldc); UNITE_SEL(out_f32);
+        UNITE_SEL(accumulate); UNITE_SEL(out_bf16_copy); UNITE_SEL(ld_copy);
+#undef UNITE_SEL
+        a_bytes = gi == 1 ? p.more_a_bytes[0] : gi == 2 ? p.more_a_bytes[1] : gi == 3 ? p.more_a_bytes[2] : a_bytes;
+        b_bytes = gi == 1 ? p.more_b_bytes[0] : gi == 2 ? p.more_b_bytes[1] : gi == 3 ? p.more_b_bytes[2] : b_bytes;
+        lin0 = gi == 1 ? p.tile_end[0] : gi == 2 ? p.tile_end[1] : gi == 3 ? p.tile_end[2] : 0;
+    }
+    const int gM = g.M, gN = g.N, gK = g.K, lda = g.lda, ldb = g.ldb;
+    const int nbn = (gN + TILE - 1) / TILE, nbm = (gM + TILE - 1) / TILE, nb = nbm * nbn;
+    const int tile = (lin - lin0) % nb, slice = (lin - lin0) / nb;
     const int m0 = (tile / nbn) * TILE, n0 = (tile % nbn) * TILE;
-    const int k_begin = slice * p.k_chunk, k_end = min(g.K, k_begin + p.k_chunk);
+    const int k_begin = slice * p.k_chunk, k_end = min(gK, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)b_bytes, 0x00020000);
 
     // half-tile load number q: K-tile u = q >> 2, kind = q & 3 (0: A0, 1: B0, 2: B1, 3: A1); slots of set (u & 1): A0 A1 B0 B1
     auto issue = [&](int q) {
@@ -358,10 +388,10 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int it = wave * 2 + i;
-            if (kind == 0) stage_piece<TA, HALF>(rsA, set, it, m0, k0, g.M, k_end, g.lda, lane);
-            else if (kind == 1) stage_piece<TB, HALF>(rsB, set + 2 * SLOT, it, n0, k0, g.N, k_end, g.ldb, lane);
-            else if (kind == 2) stage_piece<TB, HALF>(rsB, set + 3 * SLOT, it, n0 + HALF, k0, g.N, k_end, g.ldb, lane);
-            else stage_piece<TA, HALF>(rsA, set + SLOT, it, m0 + HALF, k0, g.M, k_end, g.lda, lane);
+            if (kind == 0) stage_piece<TA, HALF>(rsA, set, it, m0, k0, gM, k_end, lda, lane);
+            else if (kind == 1) stage_piece<TB, HALF>(rsB, set + 2 * SLOT, it, n0, k0, gN, k_end, ldb, lane);
+            else if (kind == 2) stage_piece<TB, HALF>(rsB, set + 3 * SLOT, it, n0 + HALF, k0, gN, k_end, ldb, lane);
+            else stage_piece<TA, HALF>(rsA, set + SLOT, it, m0 + HALF, k0, gM, k_end, lda, lane);
         }
     };
 
@@ -494,7 +524,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             const int lr = (tid + e * 4 * HALF) / CPR;
             const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
             const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
-            if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
+            if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
         }
         __syncthreads();
     }
@@ -670,8 +700,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     const int gn = n0 + nh * 128 + bcol + 16 * G;
-                    if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, acc[h][i][nh][0], acc[h][i][nh][1], bb[nh][0], bb[nh][1]);
-                    if (gm < g.M && gn + 8 < g.N) epilogue_chunk(p, slice, gm, gn + 8, acc[h][i][nh][2], acc[h][i][nh][3], bb[nh][2], bb[nh][3]);
+                    if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, acc[h][i][nh][0], acc[h][i][nh][1], bb[nh][0], bb[nh][1]);
+                    if (gm < g.M && gn + 8 < g.N) epilogue_chunk(p, g, slice, gm, gn + 8, acc[h][i][nh][2], acc[h][i][nh][3], bb[nh][2], bb[nh][3]);
                 }
             }
         return;
@@ -696,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
             const int lr = (tid >> 5) + e * 8;
             const int gm = m0 + h * 64 + lr, gn = n0 + ccol;
             const float* cp = cs + lr * TN + (ccol ^ (((lr >> 2) & 3) << 4));
-            if (gm < g.M && gn < g.N) epilogue_chunk(p, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
+            if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
         }
         __syncthreads();
     }
@@ -760,9 +790,9 @@ ProfState g_prof;
 
 }  // namespace
 
-extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
-    if (!args) return UNITE_EINVAL;
-    const unite_gemm_args& g = *args;
+namespace {
+// argument checks shared by the single and the grouped entry point; returns the operand extents for the buffer descriptors
+int check_problem(const unite_gemm_args& g, int64_t& a_bytes, int64_t& b_bytes) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.out) return UNITE_EINVAL;
     if ((g.lda & 7) || (g.ldb & 7) || (g.N & 7) || (g.ldc & 7)) return UNITE_EINVAL;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.out)) return UNITE_EINVAL;
@@ -775,12 +805,72 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     if (g.out_bf16_copy && (g.ld_copy & 7)) return UNITE_EINVAL;
     const int64_t a_rows = g.trans_a ? g.K : g.M, a_cols = g.trans_a ? g.M : g.K;
     const int64_t b_rows = g.trans_b ? g.K : g.N, b_cols = g.trans_b ? g.N : g.K;
-    const int64_t a_bytes = ((a_rows - 1) * g.lda + a_cols) * 2, b_bytes = ((b_rows - 1) * g.ldb + b_cols) * 2;
+    a_bytes = ((a_rows - 1) * g.lda + a_cols) * 2;
+    b_bytes = ((b_rows - 1) * g.ldb + b_cols) * 2;
     if (a_bytes >= (int64_t)OOB_OFFSET || b_bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
+    return UNITE_OK;
+}
+}  // namespace
+
+// Several independent problems with the same operand layouts in ONE launch of the 128 x 128 deep kernel: the four weight
+// gradients of a transformer block (K = tokens, outputs of 36..144 tiles each) fill the chip together (432 tiles over 512
+// resident workgroups) instead of each going through split-K slabs and a reduction pass.
+extern "C" int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t count, void* stream) {
+    if (!args || count <= 0 || count > MAX_GROUP) return UNITE_EINVAL;
+    if (count == 1) return unite_gemm_bf16(args, stream);
     Params p;
+    memset(&p, 0, sizeof(p));
+    int tiles = 0, kmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const unite_gemm_args& g = args[i];
+        int64_t ab, bb;
+        const int rc = check_problem(g, ab, bb);
+        if (rc != UNITE_OK) return rc;
+        if (g.trans_a != args[0].trans_a || g.trans_b != args[0].trans_b) return UNITE_EINVAL;
+        if (i == 0) { p.a = g; p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb; }
+        else { p.more[i - 1] = g; p.more_a_bytes[i - 1] = (uint32_t)ab; p.more_b_bytes[i - 1] = (uint32_t)bb; }
+        tiles += ((g.M + 127) / 128) * ((g.N + 127) / 128);
+        p.tile_end[i] = tiles;
+        kmax = g.K > kmax ? g.K : kmax;
+    }
+    p.ngroups = count;
+    p.splitk = 1;
+    p.k_chunk = (kmax + BK - 1) / BK * BK;
+    p.slab = nullptr;
+    static const int dbg = getenv("UNITE_GEMM_DEBUG_SKIP") ? atoi(getenv("UNITE_GEMM_DEBUG_SKIP")) : 0;
+    p.debug_skip = dbg;
+    p.nt_store = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
+    if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
+    const bool ta = args[0].trans_a, tb = args[0].trans_b;
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false>), dim3(tiles), dim3(256), 8 * 64 * 128, s, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true>), dim3(tiles), dim3(256), 8 * 64 * 128, s, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false>), dim3(tiles), dim3(256), 8 * 64 * 128, s, p);
+    else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true>), dim3(tiles), dim3(256), 8 * 64 * 128, s, p);
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+        g_prof.used++;
+        for (int i = 0; i < count; ++i) g_prof.flops += 2.0 * args[i].M * args[i].N * args[i].K;
+    }
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
+    if (!args) return UNITE_EINVAL;
+    const unite_gemm_args& g = *args;
+    int64_t a_bytes, b_bytes;
+    {
+        const int rc = check_problem(g, a_bytes, b_bytes);
+        if (rc != UNITE_OK) return rc;
+    }
+    Params p;
+    memset(&p, 0, sizeof(p));
     p.a = g;
     p.a_bytes = (uint32_t)a_bytes;
     p.b_bytes = (uint32_t)b_bytes;
+    p.ngroups = 1;
     // kernel + split-K choice; UNITE_GEMM_KERNEL = simple | deep128 | deep256 | wide pins the kernel (A/B experiments)
     static const char* force = getenv("UNITE_GEMM_KERNEL");
     const int only = !force ? 0 : !strcmp(force, "deep256") ? 2 : !strcmp(force, "wide") ? 3 : 1;

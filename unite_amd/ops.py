@@ -52,6 +52,28 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
          out_bf16_copy: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views."""
     lib = _lib.load()
+    g = _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scale, rows_per_scale, residual, accumulate,
+                   out_bf16_copy, workspace)
+    _lib.check(lib.unite_gemm_bf16(C.byref(g), _stream()), "unite_gemm_bf16")
+    return out
+
+
+def gemm_grouped(problems):
+    """problems: up to 4 tuples (a, b, out, kwargs-of-gemm) with equal trans_a / trans_b -> one launch (unite_gemm_bf16_grouped)."""
+    lib = _lib.load()
+    arr = (_lib.GemmArgs * len(problems))()
+    for i, (a, b, out, kw) in enumerate(problems):
+        kw = dict(kw)
+        arr[i] = _gemm_args(a, b, out, kw.pop("trans_a", False), kw.pop("trans_b", False), kw.pop("bias", None), kw.pop("act", ACT_NONE),
+                            kw.pop("aux_in", None), kw.pop("aux_out", None), kw.pop("row_scale", None), kw.pop("rows_per_scale", 1),
+                            kw.pop("residual", None), kw.pop("accumulate", False), kw.pop("out_bf16_copy", None), None)
+        if kw:
+            raise TypeError(f"unknown gemm arguments {sorted(kw)}")
+    _lib.check(lib.unite_gemm_bf16_grouped(arr, len(problems), _stream()), "unite_gemm_bf16_grouped")
+
+
+def _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scale, rows_per_scale, residual, accumulate,
+               out_bf16_copy, workspace):
     _req(a, BF16, "a"); _req(b, BF16, "b")
     M, N = out.shape
     K = a.shape[0] if trans_a else a.shape[1]
@@ -80,8 +102,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
     g.out, g.ldc, g.out_f32, g.accumulate = _ptr(out), out.stride(0), int(out.dtype == F32), int(accumulate)
     g.out_bf16_copy, g.ld_copy = _ptr(out_bf16_copy), (out_bf16_copy.stride(0) if out_bf16_copy is not None else 0)
     g.workspace, g.workspace_bytes = _ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
-    _lib.check(lib.unite_gemm_bf16(C.byref(g), _stream()), "unite_gemm_bf16")
-    return out
+    return g
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, y: torch.Tensor, *, row_index=None, post_add=None,
