@@ -161,6 +161,10 @@ int unite_resize_bicubic(const float* src, float* dst, int32_t planes, int32_t H
 int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modulo, float* out,
                           int32_t n_rows, int32_t D, void* stream);
 
+/* out[i,:] = table[index[i], :] for bf16 rows (D % 8 == 0): the visible rows of the teacher's last attention output, so
+ * that the rest of its last block runs on the 20 % of the tokens whose features are used (clip.py:100-104,168-173). */
+int unite_gather_rows_bf16(const void* table, const int32_t* index, void* out, int32_t n_rows, int32_t D, void* stream);
+
 /* CLIP token assembly + ln_pre (clip.py:148-152): patches bf16 [BT*HW, D] ->
  * x f32 [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding). */
 int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,

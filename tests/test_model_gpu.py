@@ -83,6 +83,32 @@ def test_teacher_patch14_vs_oracle():
     torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=5e-2)
 
 
+def test_teacher_last_block_not_a_tap_vs_oracle():
+    """taps (0, 1) of 3 blocks: the last block then only contributes its CLS attention row (clip.py:95-96) -- the HIP teacher
+    stops after that block's qkv projection; features and attention must still match the oracle.  Visible-row targets of a
+    model whose last block IS a tap go through the pruned path (out_proj + MLP on the listed rows only): compared row by row."""
+    from unite_amd.clip import VisionTransformer
+    vid = make_videos(2, 2, 32, 32, seed=41)
+    for taps in ((0, 1), (1, 2)):
+        cfg = O.TeacherCfg(input_resolution=32, patch_size=16, width=128, layers=3, heads=2, output_dim=64, clip_return_layers=taps)
+        t = VisionTransformer(input_resolution=32, patch_size=16, width=128, layers=3, heads=2, output_dim=64, return_attn=True,
+                              clip_return_layers=list(taps))
+        sd = fill_state_dict(teacher_shapes(cfg), 40)
+        t.load_state_dict(sd)
+        t = t.to(DEV).eval()
+        feats, attn = t(vid.to(DEV))
+        ref_f, ref_a = O.teacher_forward(sd, vid, cfg, return_attn=True)
+        assert cos_min(feats.cpu(), ref_f) >= 0.999
+        torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=5e-2)
+        # a subset of rows in scrambled order (row = frame * 5 + 1 + patch: CLS rows are skipped)
+        rows = torch.tensor([6, 1, 19, 13, 2, 17], dtype=torch.int32, device=DEV)
+        t.forward_attention(vid.to(DEV))
+        sub = t.visible_targets(rows, 6).view(2, 6, 64).cpu()
+        frame, patch = (rows.cpu() // 5).long(), (rows.cpu() % 5 - 1).long()
+        want = ref_f.reshape(2, 2, 2, 4, 64)[:, frame // 2, frame % 2, patch]          # (K, B, T, HW, C) indexed per row
+        assert cos_min(sub, want) >= 0.999
+
+
 def test_stage1_step_with_resized_patch14_teacher_vs_oracle():
     """cfg-5 geometry in miniature: student 32 x 32 @ patch 16, teacher 28 x 28 @ patch 14 (both 2 x 2 grids), clips resized
     32 -> 28 bicubically for the teacher only (run_stage1.py:362-370)."""

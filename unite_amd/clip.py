@@ -197,10 +197,20 @@ class _TeacherRuntime:
         a = ws.get("a", (Mt, 4 * D), BF16)
         scale = 64 ** -0.5
         self._tap_bufs = []
+        self._last = None
+        last = self.layers - 1
         for i in range(self.layers):
             w = self.blk[i]
             ops.layernorm_fwd(x, w["ln1"][0], w["ln1"][1], self.eps, h)
             ops.gemm(h, w["w_in"], qkv, bias=w["b_in"])
+            if i == last:
+                # Only the CLS attention row of the last block is needed for every token (the mask weights, clip.py:95-96,183).
+                # If the block is a tap, the rest of it (out_proj, MLP) runs in targets() on the rows whose features are used
+                # (320 of 1568 per clip); if not, nothing else of it is needed at all.
+                if i in self.taps:
+                    ops.attn_fwd(qkv, o, lse, BT, L, H, scale)
+                    self._last = dict(x=x, o=o)
+                break
             ops.attn_fwd(qkv, o, lse, BT, L, H, scale)
             ops.gemm(o, w["w_out"], x1, bias=w["b_out"], residual=x)
             ops.layernorm_fwd(x1, w["ln2"][0], w["ln2"][1], self.eps, h)
@@ -216,13 +226,32 @@ class _TeacherRuntime:
         ops.attn_cls_probs(qkv, attn, BT, L, H, scale)          # qkv still holds the last block's projections
         return attn
 
+    def _last_block_rows(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
+        """out_proj + MLP of the last block on the listed token rows only -> x_out f32 [n_rows, D] (same arithmetic per row)."""
+        ws, D, w = self.ws, self.D, self.blk[self.layers - 1]
+        st = self._last
+        o_v = ops.gather_rows(st["o"], rows, ws.get("last.o", (n_rows, D), BF16))
+        x_v = ops.gather_rows(st["x"], rows, ws.get("last.x", (n_rows, D), F32))
+        x1 = ws.get("last.x1", (n_rows, D), F32)
+        ops.gemm(o_v, w["w_out"], x1, bias=w["b_out"], residual=x_v)
+        hh = ws.get("last.h", (n_rows, D), BF16)
+        ops.layernorm_fwd(x1, w["ln2"][0], w["ln2"][1], self.eps, hh)
+        aa = ws.get("last.a", (n_rows, 4 * D), BF16)
+        ops.gemm(hh, w["w_fc"], aa, bias=w["b_fc"], act=ops.ACT_QUICKGELU)
+        xo = ws.get("last.xo", (n_rows, D), F32)
+        ops.gemm(aa, w["w_pr"], xo, bias=w["b_pr"], residual=x1)
+        return xo
+
     def targets(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
         ws, D, C = self.ws, self.D, self.C
         K = len(self.taps)
         out = ws.get("targets", (K * n_rows, C), F32)
         xn = ws.get("tail.xn", (n_rows, D), BF16)
         for k in range(K):
-            ops.layernorm_fwd(self._tap_bufs[k], self.ln_post[0], self.ln_post[1], self.eps, xn, row_index=rows)
+            if self._last is not None and k == K - 1:          # the last block's tap exists for these rows only
+                ops.layernorm_fwd(self._last_block_rows(rows, n_rows), self.ln_post[0], self.ln_post[1], self.eps, xn)
+            else:
+                ops.layernorm_fwd(self._tap_bufs[k], self.ln_post[0], self.ln_post[1], self.eps, xn, row_index=rows)
             ops.gemm(xn, self.proj_w, out[k * n_rows:(k + 1) * n_rows], trans_b=True)
         ops.l2_normalize_rows(out)
         return out

@@ -472,6 +472,15 @@ extern "C" int unite_im2col_gather(const float* video, const int32_t* token_inde
     return UNITE_OK;
 }
 
+extern "C" int unite_gather_rows_bf16(const void* table, const int32_t* index, void* out, int32_t n_rows, int32_t D, void* stream) {
+    if (!table || !index || !out || n_rows <= 0 || D <= 0 || (D & 7)) return UNITE_EINVAL;
+    // a bf16 row of D elements is a row of D/2 dwords: the f32 kernel moves 16 bytes per lane either way
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)table, index, 0, (float*)out,
+                       n_rows, D / 2);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
 extern "C" int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modulo, float* out, int32_t n_rows, int32_t D,
                                      void* stream) {
     if (!table || !out || n_rows <= 0 || D <= 0 || (D & 3)) return UNITE_EINVAL;

@@ -196,6 +196,11 @@ def resize_bicubic(video, out):
 
 def gather_rows(table, index, out, modulo: int = 0):
     lib = _lib.load()
+    if table.dtype == BF16:
+        _req(out, BF16, "out")
+        assert modulo == 0 and index is not None
+        _lib.check(lib.unite_gather_rows_bf16(_ptr(table), _ptr(index), _ptr(out), out.shape[0], out.shape[1], _stream()), "unite_gather_rows_bf16")
+        return out
     _lib.check(lib.unite_gather_rows_f32(_ptr(table), _ptr(index), modulo, _ptr(out), out.shape[0], out.shape[1], _stream()),
                "unite_gather_rows_f32")
     return out
