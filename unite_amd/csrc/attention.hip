@@ -16,6 +16,7 @@
 // source address; rows >= N read as zero through the buffer descriptor's range check.
 #include "attn_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -49,25 +50,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         for (int kt = 0; kt < NT16; ++kt) {
             f32x4 s = mfma16(row_frag(Ks, kt * 16, 0, lane), qf0, (f32x4){0.f, 0.f, 0.f, 0.f});
             s = mfma16(row_frag(Ks, kt * 16, 1, lane), qf1, s);
-            if (kt * 16 + 16 > N) {      // wave-uniform: only the tile(s) straddling / beyond N need the key mask
+            if (kt >= NT16 - 2) {        // 16 (NT16 - 2) < N <= 16 NT16 (host): only the last two key tiles can hold keys beyond N
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + 4 * G + r >= N) s[r] = -INFINITY;
             }
-            m = fmaxf(fmaxf(m, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+            m = max3(max3(m, s[0], s[1]), s[2], s[3]);
             st[kt] = s;
         }
         m = group_max(m);
-        float sum = 0.f;
+        const float ml2 = m * sl2;
+        float sum4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NT16; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f((st[kt][r] - m) * sl2);      // v_exp_f32; exp2(-inf) = 0 for masked keys
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], sl2, -ml2));   // one FMA + v_exp_f32; exp2(-inf) = 0
                 st[kt][r] = p;
-                sum += p;
+                sum4[r] += p;
             }
-        sum = group_sum(sum);
+        float sum = group_sum((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                 dp = mfma16(row_frag(Vs, kt * 16, 1, lane), df1, dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l2);
-                    if (kt * 16 + 16 > N && kt * 16 + 4 * G + r >= N) p = 0.f;      // keys beyond N (boundary tiles only)
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -l2));
+                    if (kt >= NT16 - 2 && kt * 16 + 4 * G + r >= N) p = 0.f;         // keys beyond N: last two key tiles only
                     ds[t][r] = p * (dp[r] - dl);
                 }
             }
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         for (int dt = 0; dt < 4; ++dt) dk[i][dt] = dv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float sl2 = scale * LOG2E;
 
-    for (int kq = 0; kq < NQ / 32; ++kq) {
+    auto qstep = [&](int kq, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;      // query rows beyond N exist only in the last 32-query step
         f32x4 P[2][KTW], dS[2][KTW];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 dp = mfma16(da1, vf[i][1], dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]);
-                    if (q0 + 16 > N && q0 + 4 * G + r >= N) p = 0.f;                 // query rows beyond N (boundary tiles only)
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -l4[r]));
+                    if (MASKED && q0 + 4 * G + r >= N) p = 0.f;
                     P[t][i][r] = p;
                     dS[t][i][r] = p * (dp[r] - d4[r]);
                 }
@@ -238,7 +241,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 dk[i][dt] = mfma16(qtr[dt], dsf, dk[i][dt]);    // dK^T[d][key]
             }
         }
-    }
+    };
+    for (int kq = 0; kq < NQ / 32 - 1; ++kq) qstep(kq, std::false_type{});
+    qstep(NQ / 32 - 1, std::true_type{});
 #pragma unroll
     for (int i = 0; i < KTW; ++i) {
         const int key = (wave * KTW + i) * 16 + c;
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }
 }
 
-inline int nt16_for(int N) { return N <= 32 ? 2 : (N <= 224 ? 14 : (N <= 320 ? 20 : 0)); }
+// key tiles of 16, even count, tight: 16 (NT16 - 2) < N <= 16 NT16, so that only the last two tiles need boundary masks
+inline int nt16_for(int N) { return N <= 320 ? 2 * ((N + 31) / 32) : 0; }
 
 // dynamic LDS above 64 KiB has to be opted into once per kernel
 template <auto Kern>
@@ -269,11 +275,13 @@ inline int set_lds(int bytes) {
 
 }  // namespace
 
-#define ATTN_DISPATCH(NT, ...)                                                                     \
-    switch (NT) {                                                                                  \
-        case 2: { constexpr int NT16 = 2; constexpr int KTW = 1; (void)KTW; __VA_ARGS__; } break;   \
-        case 14: { constexpr int NT16 = 14; constexpr int KTW = 2; (void)KTW; __VA_ARGS__; } break; \
-        default: { constexpr int NT16 = 20; constexpr int KTW = 3; (void)KTW; __VA_ARGS__; } break; \
+#define ATTN_CASE(V, W, ...) case V: { constexpr int NT16 = V; constexpr int KTW = W; (void)KTW; __VA_ARGS__; } break;
+#define ATTN_DISPATCH(NT, ...)                                                                                                   \
+    switch (NT) {                                                                                                                \
+        ATTN_CASE(2, 1, __VA_ARGS__) ATTN_CASE(4, 1, __VA_ARGS__) ATTN_CASE(6, 1, __VA_ARGS__) ATTN_CASE(8, 1, __VA_ARGS__)      \
+        ATTN_CASE(10, 2, __VA_ARGS__) ATTN_CASE(12, 2, __VA_ARGS__) ATTN_CASE(14, 2, __VA_ARGS__) ATTN_CASE(16, 2, __VA_ARGS__) \
+        ATTN_CASE(18, 3, __VA_ARGS__)                                                                                            \
+        default: { constexpr int NT16 = 20; constexpr int KTW = 3; (void)KTW; __VA_ARGS__; } break;                              \
     }
 
 int attn_fwd_tiled_launch(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, hipStream_t stream);

@@ -16,11 +16,16 @@ __device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, i
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rows32, int dt, int lane) {
     const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int r_lo = rows32 + 4 * G + q, r_hi = r_lo + 16;
-    const s16x4 lo = lds_read_tr16(tile + r_lo * 128 + ((dt ^ ((r_lo >> 1) & 3)) << 5) + 8 * p);
-    const s16x4 hi = lds_read_tr16(tile + r_hi * 128 + ((dt ^ ((r_hi >> 1) & 3)) << 5) + 8 * p);
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    // the two 8-byte halves are joined as dwords: element-wise construction of the 8 x 16-bit vector costs ~16 SDWA / shift ops
+    const u32x2 lo = __builtin_bit_cast(u32x2, lds_read_tr16(tile + r_lo * 128 + ((dt ^ ((r_lo >> 1) & 3)) << 5) + 8 * p));
+    const u32x2 hi = __builtin_bit_cast(u32x2, lds_read_tr16(tile + r_hi * 128 + ((dt ^ ((r_hi >> 1) & 3)) << 5) + 8 * p));
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8, v);
 }
+// plain fmaxf nest: the attention objects are built with -fno-honor-nans (Makefile), which drops the canonicalising v_max x,x
+// in front of every maxnum and lets the compiler form v_max3_f32.  (Inline asm is not an option for values that come straight
+// out of an MFMA: the hazard recogniser does not see into it.)
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
     u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
     return __builtin_bit_cast(bf16x8, w);

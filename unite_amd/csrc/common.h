@@ -29,8 +29,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
+// both halves in ONE v_cvt_pk_bf16_f32 (the scalar casts + shift + or form costs four VALU instructions per pair)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
