@@ -35,15 +35,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
     stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
     stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
+    // this wave's query fragments (q-tiles wave, wave + 4, ...) are fetched under the K / V staging: a global load at the top of
+    // every q-tile would expose a full HBM round trip (~2 us) per ~0.6 us of work
+    constexpr int MAXQ = (NT16 + 3) / 4;
+    bf16x8 qfr[MAXQ][2];
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+        const int qc = min((wave + 4 * qi) * 16 + c, N - 1);
+        const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
+        qfr[qi][0] = *(const bf16x8*)qp;
+        qfr[qi][1] = *(const bf16x8*)(qp + 32);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const float sl2 = scale * LOG2E;
     const int nqt = (N + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        const int q = qt * 16 + c, qc = min(q, N - 1);
-        const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
-        const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+        const int qt = wave + 4 * qi;
+        if (qt >= nqt) break;
+        const int q = qt * 16 + c;
+        const bf16x8 qf0 = qfr[qi][0], qf1 = qfr[qi][1];
         f32x4 st[NT16];
         float m = -INFINITY;
 #pragma unroll
@@ -106,24 +119,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
     stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
     stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     const float sl2 = scale * LOG2E;
     const int nqt = (N + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        const int q = qt * 16 + c, qc = min(q, N - 1);
+    // per-q-tile operands (Q, dO, O rows and the LSE) are fetched one q-tile ahead: the loads of tile i+1 fly under the ~1 us of
+    // MFMA / softmax work of tile i instead of stalling every iteration for an HBM round trip
+    bf16x8 nq0, nq1, nd0, nd1, no0, no1;
+    float nl2;
+    auto fetch = [&](int qt) {
+        const int qc = min(qt * 16 + c, N - 1);
         const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
         const uint16_t* dop = dout + (size_t)(b * N + qc) * HD + h * 64 + 8 * G;
         const uint16_t* oop = out + (size_t)(b * N + qc) * HD + h * 64 + 8 * G;
-        const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
-        const bf16x8 df0 = *(const bf16x8*)dop, df1 = *(const bf16x8*)(dop + 32);
-        const bf16x8 of0 = *(const bf16x8*)oop, of1 = *(const bf16x8*)(oop + 32);
+        nq0 = *(const bf16x8*)qp; nq1 = *(const bf16x8*)(qp + 32);
+        nd0 = *(const bf16x8*)dop; nd1 = *(const bf16x8*)(dop + 32);
+        no0 = *(const bf16x8*)oop; no1 = *(const bf16x8*)(oop + 32);
+        nl2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+    };
+    fetch(wave);             // under the K / V staging (waited for below together with it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + c;
+        const bf16x8 qf0 = nq0, qf1 = nq1, df0 = nd0, df1 = nd1, of0 = no0, of1 = no1;
+        const float l2 = nl2;
+        if (qt + 4 < nqt) fetch(qt + 4);
         float dl = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dl += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
         dl = group_sum(dl);
-        const float l2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
         if (q < N && G == 0) delta[((size_t)b * H + h) * N + q] = dl;
         f32x4 dq[4];
 #pragma unroll
