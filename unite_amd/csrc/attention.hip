@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NT16 / 2; ++kk) {
+        // 32 keys per step.  NOT fully unrolled: with all NT16 / 2 steps in one block the scheduler hoists every K / V fragment read to
+        // the top and the kernel spills (168 VGPRs at NT16 = 20: 100 us instead of 45); keys beyond N only exist in the last step.
+        auto kstep = [&](int kk, auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
             f32x4 ds[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -165,14 +167,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -l2));
-                    if (kt >= NT16 - 2 && kt * 16 + 4 * G + r >= N) p = 0.f;         // keys beyond N: last two key tiles only
+                    if (MASKED && kt * 16 + 4 * G + r >= N) p = 0.f;
                     ds[t][r] = p * (dp[r] - dl);
                 }
             }
             const bf16x8 dsf = pack_pair(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag(Ks, kk * 32, dt, lane), dsf, dq[dt]);   // dQ^T[d][q]
-        }
+        };
+        int nsteps = NT16 / 2 - 1;
+        asm volatile("" : "+s"(nsteps));            // opaque trip count: a constant odd one is unrolled completely whatever the pragma says
+        for (int kk = 0; kk < nsteps; ++kk) kstep(kk, std::false_type{});
+        kstep(NT16 / 2 - 1, std::true_type{});
         if (q < N) {
             uint16_t* op = dqkv + (size_t)(b * N + q) * ld + h * 64 + 4 * G;
 #pragma unroll
