@@ -45,6 +45,27 @@ struct Params {
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
 };
 
+// ds_read_b64_tr_b16 through inline asm.  With the builtin, hipcc cannot tell that the read does not alias the LDS-DMA writes in
+// flight and puts `s_waitcnt vmcnt(0)` in front of the first transposing read of EVERY phase: the counted vmcnt(8) pipeline of the
+// k-strided operand layouts (dgrad, wgrad) was drained four times per K-tile.  The asm read is invisible to the compiler's
+// wait-count tracking, so every phase that uses it ends its reads with lds_tr_fence() (lgkmcnt(0) + sched_barrier, guide rule 18).
+__device__ __forceinline__ u32x2 lds_read_tr16_raw(const char* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(LDS_AS const char*)p));
+    return v;
+}
+__device__ __forceinline__ bf16x8 tr_join(u32x2 lo, u32x2 hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <bool ANY_TR>
+__device__ __forceinline__ void lds_tr_fence() {
+    if (ANY_TR) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // Stage one 128 x 64 operand tile.  TR == false: memory is [rows][k] (ld elements per row);
@@ -82,10 +103,8 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
         const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
         const int ch = (row0 >> 3) + (p >> 1);
         const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
-        const s16x4 lo = lds_read_tr16(lds_tile + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (p & 1));
-        const s16x4 hi = lds_read_tr16(lds_tile + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (p & 1));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
+        return tr_join(lds_read_tr16_raw(lds_tile + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (p & 1)),
+                       lds_read_tr16_raw(lds_tile + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (p & 1)));
     }
 }
 
@@ -227,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const Params p) {
             for (int i = 0; i < 4; ++i) af[i] = load_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = load_frag<TB>(cur + TILE_BYTES, wn * 64 + j * 16, ks, lane);
+            lds_tr_fence<TA || TB>();
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -309,10 +329,8 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* slot, int row0, int ks
     const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int c32 = row0 >> 4;
     const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
-    const s16x4 lo = lds_read_tr16(slot + 128 * k_lo + ((c32 ^ swz128t(k_lo)) << 5) + 8 * pp);
-    const s16x4 hi = lds_read_tr16(slot + 128 * k_hi + ((c32 ^ swz128t(k_hi)) << 5) + 8 * pp);
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return tr_join(lds_read_tr16_raw(slot + 128 * k_lo + ((c32 ^ swz128t(k_lo)) << 5) + 8 * pp),
+                   lds_read_tr16_raw(slot + 128 * k_hi + ((c32 ^ swz128t(k_hi)) << 5) + 8 * pp));
 }
 
 // B fragment of the wide kernel with the n <-> MFMA-row permutation  n = bcol + 16 (rho >> 2) + 4 j + (rho & 3):
@@ -330,10 +348,8 @@ __device__ __forceinline__ bf16x8 load_bfrag_perm(const char* slot, int bcol, in
         const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int ch = (bcol >> 3) + 2 * pp + (j >> 1);
         const int k_lo = ks * 32 + 8 * G + q, k_hi = k_lo + 4;
-        const s16x4 lo = lds_read_tr16(slot + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (j & 1));
-        const s16x4 hi = lds_read_tr16(slot + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (j & 1));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
+        return tr_join(lds_read_tr16_raw(slot + 256 * k_lo + ((ch ^ swz256(k_lo)) << 4) + 8 * (j & 1)),
+                       lds_read_tr16_raw(slot + 256 * k_hi + ((ch ^ swz256(k_hi)) << 4) + 8 * (j & 1)));
     }
 }
 
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b0f[j][ks] = load_frag_h<TB, HALF>(B0, bcol + j * 16, ks, lane);
         issue(gph + 6);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b1f[j][ks] = load_frag_h<TB, HALF>(B1, bcol + j * 16, ks, lane);
         issue(gph + 7);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -466,6 +484,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, HALF>(A1, arow + i * 16, ks, lane);
         issue(gph + 8);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -477,6 +496,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 
         // ---- phase 4: quadrant (1,0); operands already in registers
         issue(gph + 9);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -610,6 +630,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 b0f[j][ks] = DIRECT ? load_bfrag_perm<TB>(B0, bcol, j, ks, lane) : load_frag_h<TB, 128>(B0, bcol + j * 16, ks, lane);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -629,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
                 b1f[j][ks] = DIRECT ? load_bfrag_perm<TB>(B1, bcol, j, ks, lane) : load_frag_h<TB, 128>(B1, bcol + j * 16, ks, lane);
         issueA(A0, 0, t + 1);
         issueB(B0, 0, t + 1);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -646,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[i][ks] = load_frag_h<TA, 64>(A1, arow + i * 16, ks, lane);
         issueB(B1, 1, t + 1);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -659,6 +682,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issueA(A1, 1, t + 1);
+        lds_tr_fence<TA || TB>();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
