@@ -361,7 +361,7 @@ class _StudentRuntime:
             k = self.taps.index(li)
             t = self._tap[k]
             out = ws.get(f"bw.dxt{li & 1}", (M, D), F32)
-            outb = ws.get("bw.dxtb", (M, D), BF16)
+            outb = ws.get(f"bw.dxtb{li % 3}", (M, D), BF16)      # rotation of 3: read by block li's side-stream weight gradients
             ops.layernorm_bwd(ws.peek(f"dec.dxn{k}"), t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
                               dx_bf16=outb, row_scale=scale, rows_per_scale=N, workspace=lnws,
                               dgamma=self.g_norm_w, dbeta=self.g_norm_b, dxsum=dxsum,

@@ -13,6 +13,7 @@ recomputation pointless).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -69,6 +70,13 @@ class ViTRunner:
         self._slots: Dict[str, tuple] = {}
         self._slot = ""
         self.scale = 64 ** -0.5                 # head_dim ** -0.5 (modeling_finetune.py:86)
+        self.wgrad_stream = os.environ.get("UNITE_WGRAD_STREAM", "1") != "0"
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.fp.device)
+        return self._side
 
     def use_slot(self, slot: str) -> None:
         """Switch the set of saved activations / scratch buffers (stage 3 runs several forward passes of different
@@ -195,21 +203,52 @@ class ViTRunner:
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
         gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
+        # Weight-gradient GEMMs and bias column sums are off the critical path (nothing in the backward chain reads them): they
+        # run on a side HIP stream behind events, concurrently with the next dgrad GEMM / LayerNorm backward / attention backward
+        # on the main stream, which leave MFMA or HBM headroom.  Their operands (dz, dx1b, dqkv, the incoming dxb) live in
+        # buffers alternated by block parity, so the main stream only has to wait for the side work of two blocks ago.
+        side = self._side_stream() if dx.is_cuda and self.wgrad_stream else None
+        main = torch.cuda.current_stream() if side is not None else None
+        done_ev = {}
+
+        def on_side(ev_fn):
+            """run ev_fn() on the side stream after everything issued so far on the main stream"""
+            if side is None:
+                ev_fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ev_fn()
+
+        def retire(j):
+            """block j's parameter gradients are complete on the main stream's timeline -> report it"""
+            if side is not None and j in done_ev:
+                main.wait_event(done_ev.pop(j))
+            if layer_done is not None:
+                layer_done(j)
+
         for i in reversed(range(n_blocks)):
             w, s = self._blk[i], self.saved[i]
+            par = i & 1
+            if side is not None and i + 2 < n_blocks:
+                retire(i + 2)                       # its side work read the parity buffers this block is about to overwrite
             # ---- MLP branch
-            dz = ws.get("bw.dz", (M, Hd), BF16)
+            dz = ws.get(f"bw.dz{par}", (M, Hd), BF16)
             ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
-            # weight gradients stay separate split-K launches right behind the GEMM that produced their operand: one grouped launch
-            # of the block's four (ops.gemm_grouped) is 12 % faster in isolation at 10 240 tokens but 2 % slower in the step (its
-            # 252 MB of operands have left the Infinity Cache by the end of the block), and slower outright beyond ~16 k tokens
-            ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
+            # (one grouped launch of the block's four weight gradients -- ops.gemm_grouped -- is 12 % faster in isolation at 10 240
+            # tokens but slower in the step: its 252 MB of operands have left the Infinity Cache by the end of the block)
+
+            def mlp_wgrads(dxb=dxb, dz=dz, w=w, s=s):
+                ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
+                ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
+                ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
+            on_side(mlp_wgrads)
             dh2 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
-            ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
             dx1 = ws.get("bw.dx1", (M, D), F32)
-            dx1b = ws.get("bw.dx1b", (M, D), BF16)
+            dx1b = ws.get(f"bw.dx1b{par}", (M, D), BF16)
             ops.layernorm_bwd(dh2, s["x1"], s["mean2"], s["rstd2"], w["norm2.weight"], dx_residual=dx, dx_out=dx1, dx_bf16=dx1b,
                               row_scale=None if dp is None else dp[i, 0], rows_per_scale=N,
                               dgamma=w["g:norm2.weight"], dbeta=w["g:norm2.bias"], dxsum=w["g:attn.proj.bias"],
@@ -217,18 +256,25 @@ class ViTRunner:
             # ---- attention branch
             do = ws.get("bw.do", (M, D), BF16)
             ops.gemm(dx1b, w["attn.proj.weight"], do, trans_b=True)
-            ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            dqkv = ws.get("bw.dqkv", (M, 3 * D), BF16)
+            on_side(lambda dx1b=dx1b, w=w, s=s: ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc,
+                                                        workspace=gws))
+            dqkv = ws.get(f"bw.dqkv{par}", (M, 3 * D), BF16)
             delta = ws.get("bw.delta", (B, H, N), F32)
             ops.attn_bwd(s["qkv"], s["o"], do, s["lse"], delta, dqkv, B, N, H, self.scale)
             dh1 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
-            ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-            ops.colsum(dqkv, w["g:qkv_bias"], csws, accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
+
+            def qkv_wgrads(dqkv=dqkv, w=w, s=s, i=i):
+                ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
+                ops.colsum(dqkv, w["g:qkv_bias"], csws, accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
+                if side is not None:
+                    done_ev[i] = torch.cuda.Event()
+                    done_ev[i].record(side)
+            on_side(qkv_wgrads)
             # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
             # branch's drop-path factor) or the patch-embed weight gradient (unscaled)
             dx0 = ws.get(f"bw.dx{i & 1}", (M, D), F32)
-            dx0b = ws.get("bw.dxb", (M, D), BF16)
+            dx0b = ws.get(f"bw.dxb{i % 3}", (M, D), BF16)     # read by block i-1's side work, rewritten by block i-3 (after retire(i-1))
             nxt_scale = None if (dp is None or i == 0) else dp[i - 1, 1]
             nxt_bias_g = self._blk[i - 1]["g:mlp.fc2.bias"] if i > 0 else self._pe_gb
             tapped = i > 0 and (i - 1) in tap_layers      # the tap hook then emits the final bf16 copy and its column sums
@@ -239,8 +285,11 @@ class ViTRunner:
             dx, dxb = dx0, dx0b
             if tapped:
                 dx, dxb = tap_hook(i - 1, dx, nxt_scale, nxt_bias_g)
-            if layer_done is not None:
+            if side is None and layer_done is not None:
                 layer_done(i)
+        if side is not None:
+            for j in sorted(done_ev, reverse=True):
+                retire(j)
         return dx, dxb
 
     def embed_backward(self, dxb: torch.Tensor):
