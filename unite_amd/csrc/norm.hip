@@ -171,37 +171,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 }
 
 // out_k[c] (+)= sum_b partial[b][k][c], k = 0..2; fixed order -> deterministic.
-// One workgroup per 16 columns (D/16 workgroups): thread (r, c) = (tid >> 4, tid & 15) sums partial rows r, r+16, ...,
-// then the 16 row groups are combined through LDS in a fixed order.
+// Grid (D / 32, 3): one workgroup per output vector k and 32 columns; thread (r, c) = (tid >> 5, tid & 31) sums partial rows
+// r, r + 8, ... (128-B coalesced, 8 independent loads in flight per thread), then the 8 row groups are combined through LDS in a
+// fixed order.  (The first version -- 16 columns x 16 row groups, all three vectors per workgroup -- ran only D / 16 = 48
+// workgroups with 64-B segments: 14.7 us per call, 36 calls per step.)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* __restrict__ out_a, float* __restrict__ out_b, float* __restrict__ out_c,
                                                               int accumulate) {
-    __shared__ float red[3][16][17];
-    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    float a = 0.f, b = 0.f, d = 0.f;
+    __shared__ float red[8][33];
+    const int k = blockIdx.y;
+    float* out = k == 0 ? out_a : (k == 1 ? out_b : out_c);
+    if (!out) return;                                   // workgroup-uniform
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float acc = 0.f;
     if (c < D) {
-        for (int i = r; i < nblocks; i += 16) {
-            a += partial[((size_t)i * 3 + 0) * D + c];
-            b += partial[((size_t)i * 3 + 1) * D + c];
-            d += partial[((size_t)i * 3 + 2) * D + c];
-        }
-    }
-    red[0][r][cl] = a;
-    red[1][r][cl] = b;
-    red[2][r][cl] = d;
-    __syncthreads();
-    if (threadIdx.x < 48) {
-        const int k = threadIdx.x >> 4, cc = blockIdx.x * 16 + cl;
-        if (cc < D) {
-            float v = 0.f;
+        const float* p = partial + (size_t)k * D + c;
+        const size_t stride = (size_t)3 * D;
+        int i = r;
+        for (; i + 56 < nblocks; i += 64) {
+            float v[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v += red[k][i][cl];
-            float* out = k == 0 ? out_a : (k == 1 ? out_b : out_c);
-            // accumulate: bit 0 -> out_a/out_b (gamma/beta gradients), bit 1 -> out_c (bias column sums)
-            const int acc = k < 2 ? (accumulate & 1) : (accumulate & 2);
-            if (out) out[cc] = acc ? out[cc] + v : v;
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(i + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
+        for (; i < nblocks; i += 8) acc += p[(size_t)i * stride];
+    }
+    red[r][cl] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < D) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += red[i][cl];
+        // accumulate: bit 0 -> out_a/out_b (gamma/beta gradients), bit 1 -> out_c (bias column sums)
+        const int accf = k < 2 ? (accumulate & 1) : (accumulate & 2);
+        out[c] = accf ? out[c] + v : v;
     }
 }
 
@@ -457,7 +462,7 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     UNITE_LAUNCH_CHECK();
     if (dxsum && !dx_bf16) return UNITE_EINVAL;
     if (dgamma || dbeta || dxsum) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32, 3), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
                            dbeta, dxsum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
@@ -484,7 +489,7 @@ extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const 
                                       loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta || dysum) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, 3), dim3(256), 0, s, (const float*)workspace, nb, C, dgamma,
                            dbeta, dysum, accumulate);
         UNITE_LAUNCH_CHECK();
     }
