@@ -156,6 +156,13 @@ class _TeacherRuntime:
                 w_fc=fp.w16(b + "mlp.c_fc.weight"), b_fc=P(b + "mlp.c_fc.bias"),
                 w_pr=fp.w16(b + "mlp.c_proj.weight"), b_pr=P(b + "mlp.c_proj.bias")))
         self._rows_cache = {}
+        self.two_streams = os.environ.get("UNITE_TEACHER_STREAMS", "2") != "1"
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def all_rows(self, BT: int) -> torch.Tensor:
         t = self._rows_cache.get(BT)
@@ -196,32 +203,58 @@ class _TeacherRuntime:
         x1 = ws.get("x1", (Mt, D), F32)
         a = ws.get("a", (Mt, 4 * D), BF16)
         scale = 64 ** -0.5
-        self._tap_bufs = []
-        self._last = None
         last = self.layers - 1
-        for i in range(self.layers):
-            w = self.blk[i]
-            ops.layernorm_fwd(x, w["ln1"][0], w["ln1"][1], self.eps, h)
-            ops.gemm(h, w["w_in"], qkv, bias=w["b_in"])
-            if i == last:
-                # Only the CLS attention row of the last block is needed for every token (the mask weights, clip.py:95-96,183).
-                # If the block is a tap, the rest of it (out_proj, MLP) runs in targets() on the rows whose features are used
-                # (320 of 1568 per clip); if not, nothing else of it is needed at all.
-                if i in self.taps:
-                    ops.attn_fwd(qkv, o, lse, BT, L, H, scale)
-                    self._last = dict(x=x, o=o)
-                break
-            ops.attn_fwd(qkv, o, lse, BT, L, H, scale)
-            ops.gemm(o, w["w_out"], x1, bias=w["b_out"], residual=x)
-            ops.layernorm_fwd(x1, w["ln2"][0], w["ln2"][1], self.eps, h)
-            ops.gemm(h, w["w_fc"], a, bias=w["b_fc"], act=ops.ACT_QUICKGELU)
-            if i in self.taps:
-                xo = ws.get(f"tap.{i}", (Mt, D), F32)      # kept until targets() gathers the visible rows
-                self._tap_bufs.append(xo)
-            else:
-                xo = ws.get("x.a", (Mt, D), F32)           # may alias x: the block input is dead after out_proj
-            ops.gemm(a, w["w_pr"], xo, bias=w["b_pr"], residual=x1)
-            x = xo
+        pruned_tap = last in self.taps
+        taps_full = {i: ws.get(f"tap.{i}", (Mt, D), F32) for i in self.taps if i != last}     # kept until targets() gathers rows
+        self._tap_bufs = [taps_full[i] for i in sorted(taps_full)]
+        self._last = dict(x=None, o=o) if pruned_tap else None
+
+        def run_layers(f0: int, f1: int):
+            """all blocks for frames [f0, f1): every buffer is used through its row slice, so two frame ranges are independent"""
+            r0, r1, nf = f0 * L, f1 * L, f1 - f0
+            xs = x[r0:r1]
+            for i in range(self.layers):
+                w = self.blk[i]
+                ops.layernorm_fwd(xs, w["ln1"][0], w["ln1"][1], self.eps, h[r0:r1])
+                ops.gemm(h[r0:r1], w["w_in"], qkv[r0:r1], bias=w["b_in"])
+                if i == last:
+                    # Only the CLS attention row of the last block is needed for every token (the mask weights, clip.py:95-96,183).
+                    # If the block is a tap, the rest of it (out_proj, MLP) runs in targets() on the rows whose features are used
+                    # (320 of 1568 per clip); if not, nothing else of it is needed at all.
+                    if pruned_tap:
+                        ops.attn_fwd(qkv[r0:r1], o[r0:r1], lse[f0:f1], nf, L, H, scale)
+                    return xs
+                ops.attn_fwd(qkv[r0:r1], o[r0:r1], lse[f0:f1], nf, L, H, scale)
+                ops.gemm(o[r0:r1], w["w_out"], x1[r0:r1], bias=w["b_out"], residual=xs)
+                ops.layernorm_fwd(x1[r0:r1], w["ln2"][0], w["ln2"][1], self.eps, h[r0:r1])
+                ops.gemm(h[r0:r1], w["w_fc"], a[r0:r1], bias=w["b_fc"], act=ops.ACT_QUICKGELU)
+                xo = taps_full[i][r0:r1] if i in taps_full else x[r0:r1]      # may alias xs: the block input is dead after out_proj
+                ops.gemm(a[r0:r1], w["w_pr"], xo, bias=w["b_pr"], residual=x1[r0:r1])
+                xs = xo
+            return xs
+
+        # Two independent halves of the frames on two HIP streams: while one half is in a LayerNorm / attention kernel (HBM- or
+        # latency-bound) or in the ragged last round of a GEMM, the other half's GEMM workgroups fill the idle CUs.
+        if self.two_streams and BT >= 16 and videos.is_cuda:
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            fh = BT // 2
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                xb = run_layers(fh, BT)
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+            xa = run_layers(0, fh)
+            main.wait_event(ev2)
+            x_last = (xa, xb)
+        else:
+            x_last = (run_layers(0, BT),)
+        if pruned_tap:
+            # the block-input rows of both halves live in ONE of the full buffers (x.a or the previous tap): the same for both
+            base = x_last[0]._base if x_last[0]._base is not None else x_last[0]
+            self._last["x"] = base
         attn = ws.get("attn", (BT, HW), F32)
         ops.attn_cls_probs(qkv, attn, BT, L, H, scale)          # qkv still holds the last block's projections
         return attn
