@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one HIP stream for the whole run (no side-stream weight gradients, no two-stream "
+                                                          "teacher): per-kernel durations are then undisturbed, as in the roofline pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of the N>1 flow on one GPU)")
     a = ap.parse_args()
 
@@ -132,6 +134,9 @@ def main():
     videos = torch.randn(B, 3, T, 224, 224, device=dev)           # synthetic, ImageNet-normalised-like; resident in HBM
     state = StepState()
     state.seed = 1000 * rank
+    if a.serial:
+        student.runtime().runner.wgrad_stream = False
+        teacher.runtime().two_streams = False
     it = [0]
 
     def step():
@@ -167,7 +172,14 @@ def main():
         print(f"[bench] timed region: {a.steps} steps in {dt:.3f} s ({dt / a.steps * 1e3:.2f} ms/step), loss {loss_v:.4f}", file=sys.stderr, flush=True)
     clips_s = total_batch * a.steps / dt
 
+    def set_concurrency(on: bool):
+        """side-stream weight gradients (student) and the two-stream teacher; off = every kernel alone on the GPU"""
+        student.runtime().runner.wgrad_stream = on
+        teacher.runtime().two_streams = on
+
     roof = None
+    if not a.no_roofline:
+        set_concurrency(False)          # kernel durations of the roofline pass must not include time shared with other kernels
     if not a.no_roofline and rank == 0:
         lib = _lib.load()
         n_prof = min(a.steps, 5)
@@ -190,13 +202,17 @@ def main():
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
-                "note": "HIP events on the launch stream around every GEMM launch in a second pass of the same step"}
+                "note": "HIP events on the launch stream around every GEMM launch in a second pass of the same steps, run on ONE stream "
+                        "(the timed region overlaps weight-gradient GEMMs and the two teacher halves on side streams, which would "
+                        "charge each launch for time it shares with other kernels); same numbers as `bench.py --serial` under rocprofv3"}
     elif world > 1:
         # keep ranks in lock-step with rank 0's profiled pass
         for _ in range(min(a.steps, 5)):
             step()
         torch.cuda.synchronize()
 
+    if not a.no_roofline:
+        set_concurrency(not a.serial)
     if rank == 0:
         out = {"metric": "stage-1 train clips/sec (ViT-B/16, 8fx224^2)", "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
