@@ -9,6 +9,7 @@
 //             dK/dV kernel: workgroup = (batch, head, 256 keys), 8 waves x 2 key tiles with K,V fragments in registers,
 //             Q/dO tiles of 32 queries double-buffered in LDS.
 #include "attn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -51,18 +52,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tiled_kernel(const uint16_t* 
         for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float sl2 = scale * LOG2E;
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one key tile; MASKED (keys beyond N) only for the last one.  The V^T fragments are read (asm, untracked) right behind the K
+    // fragments so that their LDS latency hides under QK^T and the softmax; the next tile's LDS-DMA stays in flight throughout.
+    auto ktile = [&](int kt, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // tile kt landed for every wave; everyone is done with the other buffer
-        if (kt + 1 < nkt) stage(kt + 1);
+        if (!MASKED) stage(kt + 1);
         const char* Ks = smem + (kt & 1) * 2 * TILE_B;
         const char* Vs = Ks + TILE_B;
-        bf16x8 kf[4][2];
+        bf16x8 kf[4][2], vf[2][4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             kf[s4][0] = row_frag(Ks, s4 * 16, 0, lane);
             kf[s4][1] = row_frag(Ks, s4 * 16, 1, lane);
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[kk][dt] = tr_frag_raw(Vs, kk * 32, dt, lane);
         bf16x8 pf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -72,42 +80,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tiled_kernel(const uint16_t* 
             for (int s4 = 0; s4 < 4; ++s4) {
                 f32x4 v = mfma16(kf[s4][0], qf[t][0], (f32x4){0.f, 0.f, 0.f, 0.f});
                 v = mfma16(kf[s4][1], qf[t][1], v);
-                if (kt == nkt - 1) {
+                if (MASKED) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (kt * TK + s4 * 16 + 4 * G + r >= N) v[r] = -INFINITY;
                 }
-                mt = fmaxf(fmaxf(mt, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                mt = max3(max3(mt, v[0], v[1]), v[2], v[3]);
                 s[s4] = v;
             }
             mt = group_max(mt);
-            const float mn = fmaxf(m[t], mt);
-            const float alpha = __builtin_amdgcn_exp2f((m[t] - mn) * sl2);      // 0 on the first tile (m = -inf)
-            float ls = 0.f;
+            const float mn = fmaxf(m[t], mt), mn2 = mn * sl2;
+            const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m[t], sl2, -mn2));      // 0 on the first tile (m = -inf)
+            float ls4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f((s[s4][r] - mn) * sl2);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[s4][r], sl2, -mn2));
                     s[s4][r] = p;
-                    ls += p;
+                    ls4[r] += p;
                 }
-            l[t] = l[t] * alpha + ls;            // per-lane partial over this lane's keys; summed across G at the end
+            l[t] = l[t] * alpha + ((ls4[0] + ls4[1]) + (ls4[2] + ls4[3]));      // per-lane partial over this lane's keys; summed across G at the end
             m[t] = mn;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){o[t][dt][0] * alpha, o[t][dt][1] * alpha, o[t][dt][2] * alpha, o[t][dt][3] * alpha};
             pf[t][0] = pack_pair(s[0], s[1]);
             pf[t][1] = pack_pair(s[2], s[3]);
         }
+        lds_tr_fence<true>();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 vf = tr_frag(Vs, kk * 32, dt, lane);
-                o[0][dt] = mfma16(vf, pf[0][kk], o[0][dt]);
-                o[1][dt] = mfma16(vf, pf[1][kk], o[1][dt]);
+                o[0][dt] = mfma16(vf[kk][dt], pf[0][kk], o[0][dt]);
+                o[1][dt] = mfma16(vf[kk][dt], pf[1][kk], o[1][dt]);
             }
-    }
+    };
+    for (int kt = 0; kt < nkt - 1; ++kt) ktile(kt, std::false_type{});
+    ktile(nkt - 1, std::true_type{});
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int q = q0 + t * 16 + c;
@@ -168,12 +178,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tiled_kernel(const uint16_
     }
     const float sl2 = scale * LOG2E;
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto ktile = [&](int kt, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;          // keys beyond N: last tile only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nkt) stage(kt + 1);
+        if (!MASKED) stage(kt + 1);
         const char* Ks = smem + (kt & 1) * 2 * TILE_B;
         const char* Vs = Ks + TILE_B;
+        bf16x8 ktr[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ktr[kk][dt] = tr_frag_raw(Ks, kk * 32, dt, lane);      // K^T for dQ: latency hides under S / dP
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -186,23 +202,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_tiled_kernel(const uint16_
                 dp = mfma16(row_frag(Vs, s4 * 16, 1, lane), df[t][1], dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l2[t]);
-                    if (kt == nkt - 1 && kt * TK + s4 * 16 + 4 * G + r >= N) p = 0.f;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -l2[t]));
+                    if (MASKED && kt * TK + s4 * 16 + 4 * G + r >= N) p = 0.f;
                     ds[s4][r] = p * (dp[r] - dl[t]);
                 }
             }
             dsf[t][0] = pack_pair(ds[0], ds[1]);
             dsf[t][1] = pack_pair(ds[2], ds[3]);
         }
+        lds_tr_fence<true>();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 ktr = tr_frag(Ks, kk * 32, dt, lane);
-                dq[0][dt] = mfma16(ktr, dsf[0][kk], dq[0][dt]);
-                dq[1][dt] = mfma16(ktr, dsf[1][kk], dq[1][dt]);
+                dq[0][dt] = mfma16(ktr[kk][dt], dsf[0][kk], dq[0][dt]);
+                dq[1][dt] = mfma16(ktr[kk][dt], dsf[1][kk], dq[1][dt]);
             }
-    }
+    };
+    for (int kt = 0; kt < nkt - 1; ++kt) ktile(kt, std::false_type{});
+    ktile(nkt - 1, std::true_type{});
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int q = q0 + t * 16 + c;
@@ -261,13 +279,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_tiled_kernel(const uint16
         for (int dt = 0; dt < 4; ++dt) dk[i][dt] = dv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float sl2 = scale * LOG2E;
 
-    for (int qs = 0; qs < nqs; ++qs) {
+    auto qstep = [&](int qs, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;          // query rows beyond N: last step only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (qs + 1 < nqs) stage(qs + 1);
+        if (!MASKED) stage(qs + 1);
         const char* Qs = smem + (qs & 1) * 2 * STEP_B;
         const char* Ds = Qs + STEP_B;
         const float* st = stats + (qs & 1) * 2 * TQ;
+        bf16x8 dot[4], qtr[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dot[dt] = tr_frag_raw(Ds, 0, dt, lane);       // dO^T, Q^T for dV / dK: asm reads, fenced before those products
+            qtr[dt] = tr_frag_raw(Qs, 0, dt, lane);
+        }
         f32x4 P[2][2], dS[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -282,23 +307,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_tiled_kernel(const uint16
                 dp = mfma16(da1, vf[i][1], dp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[r] * sl2 - l4[r]);
-                    if (qs == nqs - 1 && qs * TQ + t * 16 + 4 * G + r >= N) p = 0.f;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -l4[r]));
+                    if (MASKED && qs * TQ + t * 16 + 4 * G + r >= N) p = 0.f;
                     P[t][i][r] = p;
                     dS[t][i][r] = p * (dp[r] - d4[r]);
                 }
             }
         }
+        lds_tr_fence<true>();
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 dot = tr_frag(Ds, 0, dt, lane), qtr = tr_frag(Qs, 0, dt, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                dv[i][dt] = mfma16(dot, pack_pair(P[0][i], P[1][i]), dv[i][dt]);
-                dk[i][dt] = mfma16(qtr, pack_pair(dS[0][i], dS[1][i]), dk[i][dt]);
+                dv[i][dt] = mfma16(dot[dt], pack_pair(P[0][i], P[1][i]), dv[i][dt]);
+                dk[i][dt] = mfma16(qtr[dt], pack_pair(dS[0][i], dS[1][i]), dk[i][dt]);
             }
         }
-    }
+    };
+    for (int qs = 0; qs < nqs - 1; ++qs) qstep(qs, std::false_type{});
+    qstep(nqs - 1, std::true_type{});
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int key = key0 + i * 16 + c;

@@ -26,6 +26,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rows32, int dt, 
 // in front of every maxnum and lets the compiler form v_max3_f32.  (Inline asm is not an option for values that come straight
 // out of an MFMA: the hazard recogniser does not see into it.)
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// the same fragment through the asm read (common.h): for loops that keep LDS-DMA tiles in flight -- with the builtin hipcc drains
+// the DMA queue (vmcnt(0)) in front of the read.  The caller ends its group of reads with lds_tr_fence<true>() before the MFMAs.
+__device__ __forceinline__ bf16x8 tr_frag_raw(const char* tile, int rows32, int dt, int lane) {
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r_lo = rows32 + 4 * G + q, r_hi = r_lo + 16;
+    return tr_join(lds_read_tr16_raw(tile + r_lo * 128 + ((dt ^ ((r_lo >> 1) & 3)) << 5) + 8 * p),
+                   lds_read_tr16_raw(tile + r_hi * 128 + ((dt ^ ((r_hi >> 1) & 3)) << 5) + 8 * p));
+}
 __device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
     u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
     return __builtin_bit_cast(bf16x8, w);

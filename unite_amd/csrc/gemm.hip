@@ -45,27 +45,6 @@ struct Params {
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
 };
 
-// ds_read_b64_tr_b16 through inline asm.  With the builtin, hipcc cannot tell that the read does not alias the LDS-DMA writes in
-// flight and puts `s_waitcnt vmcnt(0)` in front of the first transposing read of EVERY phase: the counted vmcnt(8) pipeline of the
-// k-strided operand layouts (dgrad, wgrad) was drained four times per K-tile.  The asm read is invisible to the compiler's
-// wait-count tracking, so every phase that uses it ends its reads with lds_tr_fence() (lgkmcnt(0) + sched_barrier, guide rule 18).
-__device__ __forceinline__ u32x2 lds_read_tr16_raw(const char* p) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(LDS_AS const char*)p));
-    return v;
-}
-__device__ __forceinline__ bf16x8 tr_join(u32x2 lo, u32x2 hi) {
-    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-template <bool ANY_TR>
-__device__ __forceinline__ void lds_tr_fence() {
-    if (ANY_TR) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // Stage one 128 x 64 operand tile.  TR == false: memory is [rows][k] (ld elements per row);
