@@ -1,0 +1,154 @@
+"""Checkpoint hand-off between the stages -- drop-in for the loaders of the reference drivers:
+
+  run_stage1.py:518-602  load_student_from_ckpt   (UMT K710 encoder  -> stage-1 student, + optional decoders)
+  run_stage2.py:349-438  load_from_ckpt           (stage-1 student   -> stage-2 classifier: 'encoder.' / 'backbone.' stripped,
+                                                   head handling, position-table interpolation)
+  run_stage3.py:829-924  load_student_from_ckpt   (stage-1/2 weights -> stage-3 student)
+
+Same ``args`` fields, same key rewrites in the same order, same ``utils.load_state_dict`` (non-strict, prefix-aware) at the end.
+Host logic only (torch CPU tensors); nothing here touches the GPU path.  The reference reads checkpoints with a plain
+``torch.load`` (they carry an argparse Namespace): ``read_checkpoint`` tries the tensor-only loader first and falls back to it.
+"""
+from __future__ import annotations
+
+import json
+from collections import OrderedDict
+
+import torch
+
+from . import utils
+
+
+def read_checkpoint(path: str):
+    if str(path).startswith("https"):
+        raise RuntimeError("remote checkpoints are not fetched (no network in this build); download the file and pass its path")
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        return torch.load(path, map_location="cpu", weights_only=False)      # user-supplied file with pickled args, as the reference
+
+
+def _select(checkpoint, model_key: str):
+    """first of the '|'-separated keys present in the file, else the file itself (run_stage1.py:523-533)"""
+    for key in model_key.split('|'):
+        if key in checkpoint:
+            print("Load state_dict by model_key = %s" % key)
+            return checkpoint[key], True
+    return checkpoint, False
+
+
+def interpolate_pos_embed(checkpoint_model, model, num_frames: int, patch_embed=None, pretrain_frames: int = 8):
+    """run_stage1.py:553-591 == run_stage2.py:396-434 == run_stage3.py:875-913: linear in time (the checkpoints were pre-trained
+    on 8 frames), then bicubic in space; class / dist tokens are kept.  In place on checkpoint_model['pos_embed']."""
+    if 'pos_embed' not in checkpoint_model:
+        return checkpoint_model
+    pe = patch_embed if patch_embed is not None else model.patch_embed
+    pos_embed_checkpoint = checkpoint_model['pos_embed']
+    embedding_size = pos_embed_checkpoint.shape[-1]
+    num_patches = pe.num_patches
+    num_extra_tokens = model.pos_embed.shape[-2] - num_patches
+    orig_t_size = pretrain_frames // pe.tubelet_size
+    new_t_size = num_frames // pe.tubelet_size
+    orig_size = int(((pos_embed_checkpoint.shape[-2] - num_extra_tokens) // orig_t_size) ** 0.5)
+    new_size = int((num_patches // new_t_size) ** 0.5)
+    if orig_t_size != new_t_size:
+        print(f"Temporal interpolate from {orig_t_size} to {new_t_size}")
+        tmp = pos_embed_checkpoint.view(1, orig_t_size, -1, embedding_size)
+        tmp = tmp.permute(0, 2, 3, 1).reshape(-1, embedding_size, orig_t_size)
+        tmp = torch.nn.functional.interpolate(tmp, size=new_t_size, mode='linear')
+        tmp = tmp.view(1, -1, embedding_size, new_t_size)
+        tmp = tmp.permute(0, 3, 1, 2).reshape(1, -1, embedding_size)
+        checkpoint_model['pos_embed'] = tmp
+        pos_embed_checkpoint = tmp
+    if orig_size != new_size:
+        print("Position interpolate from %dx%d to %dx%d" % (orig_size, orig_size, new_size, new_size))
+        extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
+        pos_tokens = pos_embed_checkpoint[:, num_extra_tokens:]
+        pos_tokens = pos_tokens.reshape(-1, new_t_size, orig_size, orig_size, embedding_size)
+        pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
+        pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size), mode='bicubic', align_corners=False)
+        pos_tokens = pos_tokens.permute(0, 2, 3, 1).reshape(-1, new_t_size, new_size, new_size, embedding_size)
+        pos_tokens = pos_tokens.flatten(1, 3)
+        checkpoint_model['pos_embed'] = torch.cat((extra_tokens, pos_tokens), dim=1)
+    return checkpoint_model
+
+
+def _strip_backbone(checkpoint_model, strip_encoder: bool):
+    new_dict = OrderedDict()
+    for key in list(checkpoint_model.keys()):
+        if key.startswith('backbone.'):
+            new_dict[key[9:]] = checkpoint_model[key]
+        elif strip_encoder and key.startswith('encoder.'):
+            new_dict[key[8:]] = checkpoint_model[key]
+        else:
+            new_dict[key] = checkpoint_model[key]
+    return new_dict
+
+
+def _finish_student(args, model, checkpoint_model):
+    if getattr(args, "clip_decoder_init", None):
+        decoder_ckpt = read_checkpoint(args.clip_decoder_init)
+        checkpoint_model.update({k: v for k, v in decoder_ckpt.items() if k.startswith('clip_decoder.')})
+        print("Loaded decoder params from %s" % args.clip_decoder_init)
+    # the reference indexes model.patch_embed / model.pos_embed here, which only exist on the encoder of the student wrapper:
+    # a learnable 'pos_embed' in the file therefore crashes it; this build interpolates against the encoder (sinusoid students
+    # simply report the key as unused, as utils.load_state_dict does)
+    enc = getattr(model, "encoder", model)
+    if 'pos_embed' in checkpoint_model and hasattr(enc, "pos_embed") and hasattr(enc, "patch_embed"):
+        interpolate_pos_embed(checkpoint_model, enc, args.num_frames)
+    utils.load_state_dict(model, checkpoint_model, prefix=getattr(args, "student_prefix", ''))
+    if getattr(args, "freeze_clip_decoders", False):
+        for name, param in model.named_parameters():
+            if name.startswith('clip_decoder.'):
+                param.requires_grad = False
+                print("Freezing %s" % name)
+    return model
+
+
+def load_student_from_ckpt(args, model):
+    """run_stage1.py:518-602: every key of the selected state_dict gets the 'encoder.' prefix (UMT encoder-only checkpoints)."""
+    print("Loading student model from %s" % args.student_init)
+    checkpoint = read_checkpoint(args.student_init)
+    checkpoint_model, found = _select(checkpoint, args.model_key)
+    if found:
+        checkpoint_model = {f'encoder.{k}': v for k, v in checkpoint_model.items()}
+    return _finish_student(args, model, _strip_backbone(checkpoint_model, strip_encoder=False))
+
+
+def load_student_from_ckpt_stage3(args, model):
+    """run_stage3.py:829-924: as stage 1, but a state_dict that already starts with 'encoder.' (a stage-1 / stage-2 output of this
+    pipeline) is taken as it is.  (The reference's two hard-wired /cis/home paths for 'umt_k710*' are site-specific and not kept.)"""
+    print("Loading student model from %s" % args.student_init)
+    checkpoint = read_checkpoint(args.student_init)
+    checkpoint_model, found = _select(checkpoint, args.model_key)
+    if found and not list(checkpoint_model.keys())[0].startswith('encoder.'):
+        checkpoint_model = {f'encoder.{k}': v for k, v in checkpoint_model.items()}
+    return _finish_student(args, model, _strip_backbone(checkpoint_model, strip_encoder=False))
+
+
+def load_from_ckpt(args, model):
+    """run_stage2.py:349-438: classifier initialisation from a pre-trained / stage-1 checkpoint."""
+    checkpoint = read_checkpoint(args.finetune)
+    print("Load ckpt from %s" % args.finetune)
+    checkpoint_model, _ = _select(checkpoint, args.model_key)
+    if 'head.weight' in checkpoint_model.keys():
+        if getattr(args, "delete_head", False):
+            print("Removing head from pretrained checkpoint")
+            del checkpoint_model['head.weight']
+            del checkpoint_model['head.bias']
+        elif checkpoint_model['head.weight'].shape[0] == 710:
+            if args.nb_classes == 400:
+                checkpoint_model['head.weight'] = checkpoint_model['head.weight'][:args.nb_classes]
+                checkpoint_model['head.bias'] = checkpoint_model['head.bias'][:args.nb_classes]
+            elif args.nb_classes in [600, 700]:
+                map_path = f'k710/label_mixto{args.nb_classes}.json'
+                print(f'Load label map from {map_path}')
+                with open(map_path) as f:
+                    label_map = json.load(f)
+                checkpoint_model['head.weight'] = checkpoint_model['head.weight'][label_map]
+                checkpoint_model['head.bias'] = checkpoint_model['head.bias'][label_map]
+    checkpoint_model = _strip_backbone(checkpoint_model, strip_encoder=True)
+    if 'pos_embed' in checkpoint_model and hasattr(model, "pos_embed"):
+        interpolate_pos_embed(checkpoint_model, model, args.num_frames)
+    utils.load_state_dict(model, checkpoint_model, prefix=getattr(args, "model_prefix", ''))
+    return model

@@ -269,6 +269,39 @@ def init_distributed_mode(args):
 
 
 # ----------------------------------------------------------------------------- checkpoints (utils.py:689-776)
+def load_state_dict(model, state_dict, prefix='', ignore_missing="relative_position_index"):
+    """reference utils.py:554-599: non-strict recursive load with a key prefix; reports missing / unused / ignored keys."""
+    missing_keys, unexpected_keys, error_msgs = [], [], []
+    metadata = getattr(state_dict, '_metadata', None)
+    state_dict = state_dict.copy()
+    if metadata is not None:
+        state_dict._metadata = metadata
+
+    def load(module, prefix=''):
+        local_metadata = {} if metadata is None else metadata.get(prefix[:-1], {})
+        module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys, unexpected_keys, error_msgs)
+        for name, child in module._modules.items():
+            if child is not None:
+                load(child, prefix + name + '.')
+
+    load(model, prefix=prefix)
+    warn_missing_keys, ignore_missing_keys = [], []
+    for key in missing_keys:
+        if any(ig in key for ig in ignore_missing.split('|')):
+            ignore_missing_keys.append(key)
+        else:
+            warn_missing_keys.append(key)
+    if len(warn_missing_keys) > 0:
+        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, warn_missing_keys))
+    if len(unexpected_keys) > 0:
+        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected_keys))
+    if len(ignore_missing_keys) > 0:
+        print("Ignored weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, ignore_missing_keys))
+    if len(error_msgs) > 0:
+        print('\n'.join(error_msgs))
+    return warn_missing_keys, unexpected_keys        # (the bf16 shadow follows by itself: FlatParams watches tensor versions)
+
+
 def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None, tag=None):
     """{'model','optimizer','epoch','scaler','args'} in checkpoint-{epoch|tag}.pth on rank 0 (utils.py:689-736)."""
     output_dir = Path(args.output_dir)
