@@ -150,6 +150,14 @@ int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, in
 int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t ld_cols,
                         int32_t n_rows, int32_t B, int32_t T, int32_t H, int32_t W, int32_t P, void* stream);
 
+/* Decoded uint8 frames (B,T,H,W,3) -> the f32 (B,3,T,H,W) clip tensor the engines take: ((x / 255) - mean[c]) / std[c] with an
+ * optional left-right flip per clip (flip: device uint8[B] or NULL).  Replaces the CPU-side GroupRandomHorizontalFlip + Stack +
+ * ToTorchFormatTensor + GroupNormalize + view/transpose of src/datasets/transforms.py:68-96,209-245 and mae.py:218-219 (the
+ * reference notes the transpose alone is "80% of the loading time"); same operation order, bit-identical.  mean3 / std3: HOST
+ * arrays of 3 floats.  W % 4 == 0. */
+int unite_clip_u8_to_f32(const uint8_t* frames, float* out, const uint8_t* flip, const float* mean3, const float* std3, int32_t B,
+                         int32_t T, int32_t H, int32_t W, void* stream);
+
 /* Bicubic resize of `planes` f32 images H x W -> OH x OW with the semantics of
  * torch.nn.functional.interpolate(mode='bicubic', align_corners=False) (A = -0.75, clamped taps):
  * the teacher-input resize of run_stage1.py:362-368 / run_stage3.py:438-445 (224 -> 196 for CLIP-L/14). */

@@ -547,3 +547,21 @@ def stage3_loss(student_sd: SD, teacher_sd: SD, cls_w: Tensor, cls_b: Tensor, vi
     else:
         loss_t = torch.zeros(())
     return src_ratio_pl * loss_s + loss_t, loss_s, loss_t, sel
+
+
+def clip_to_tensor(frames_u8: Tensor, mean: Sequence[float], std: Sequence[float], flip: Optional[Tensor] = None) -> Tensor:
+    """Input path after decode/crop/resize: GroupRandomHorizontalFlip (transforms.py:68-79), Stack (:209-223), ToTorchFormatTensor
+    (:226-245: HWC -> CHW, .float().div(255.)), GroupNormalize (:82-96: t.sub_(m).div_(s) per channel), then mae.py:218-219
+    view (T,3,H,W) -> transpose -> (3,T,H,W).  frames_u8: (B,T,H,W,3) uint8; flip: bool/uint8 (B,) -> (B,3,T,H,W) f32."""
+    out = []
+    for b in range(frames_u8.shape[0]):
+        fr = frames_u8[b]
+        if flip is not None and bool(flip[b]):
+            fr = fr.flip(2)                                            # FLIP_LEFT_RIGHT of every frame
+        stacked = torch.cat([f for f in fr], dim=2)                    # H x W x 3T
+        img = stacked.permute(2, 0, 1).contiguous().float().div(255.)  # 3T x H x W
+        rep_mean, rep_std = list(mean) * (img.shape[0] // 3), list(std) * (img.shape[0] // 3)
+        for t, m, s in zip(img, rep_mean, rep_std):
+            t.sub_(m).div_(s)
+        out.append(img.view((fr.shape[0], 3) + img.shape[-2:]).transpose(0, 1))
+    return torch.stack(out)

@@ -370,6 +370,23 @@ def test_resize_bicubic_matches_torch_interpolate(ops, H, W, OH, OW):
     torch.testing.assert_close(out.cpu(), ref, atol=1e-5, rtol=1e-5)
 
 
+def test_clip_u8_to_f32_bit_exact_vs_reference_transform_order(ops):
+    """GPU input path (flip + HWC->CHW + /255 + normalise) == the oracle's restatement of the reference transforms, bit for bit."""
+    from unite_amd.data import ClipToTensor, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (3, 4, 32, 48, 3), generator=g, dtype=torch.uint8)
+    flip = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    ref = O.clip_to_tensor(frames, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, flip)
+    out = ClipToTensor()(frames.to(DEV), flip.to(DEV))
+    assert out.shape == ref.shape == (3, 3, 4, 32, 48)
+    assert torch.equal(out.cpu(), ref)
+    out2 = ClipToTensor()(frames.to(DEV))
+    assert torch.equal(out2.cpu(), O.clip_to_tensor(frames, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD))
+    # every byte value through the two divisions
+    ramp = torch.arange(256, dtype=torch.uint8).view(1, 1, 1, 256, 1).expand(1, 1, 1, 256, 3).contiguous()
+    assert torch.equal(ClipToTensor()(ramp.to(DEV)).cpu(), O.clip_to_tensor(ramp, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD))
+
+
 def test_clip_embed_ln_and_l2(ops):
     BT, HW, D = 3, 196, 768
     patches = bf(rnd(BT * HW, D, seed=1))

@@ -341,6 +341,42 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(const float* __rest
     dst[((size_t)blockIdx.z * OH + oy) * OW + ox] = acc;
 }
 
+// ------------------------------------------------------------------------------------ clip frames -> training tensor
+// uint8 (B,T,H,W,3) decoded frames -> f32 (B,3,T,H,W): ((x / 255) - mean[c]) / std[c], optional left-right flip per clip.
+// The arithmetic order (two correctly rounded f32 divisions, one subtraction) is the reference's ToTorchFormatTensor +
+// GroupNormalize (src/datasets/transforms.py:93-94,245), so the result is bit-identical to its CPU pipeline.  One thread = 4
+// pixels of a row: 12 contiguous input bytes (a wave reads 768 B), one 16-B store per channel plane.
+__global__ __launch_bounds__(256) void clip_u8_to_f32_kernel(const uint8_t* __restrict__ frames, float* __restrict__ out,
+                                                             const uint8_t* __restrict__ flip, float m0, float m1, float m2, float s0, float s1,
+                                                             float s2, int T, int H, int W, size_t n_quads) {
+    const int W4 = W >> 2;
+    const size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += (size_t)gridDim.x * 256) {
+        const int xq = (int)(i % W4);
+        const size_t row = i / W4;                      // ((b * T + t) * H + y)
+        const int y = (int)(row % H);
+        const size_t bt = row / H;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const bool fl = flip && flip[b];
+        const int x0 = fl ? W - 4 - 4 * xq : 4 * xq;    // source quad; its pixels are reversed below when flipped
+        const uint8_t* src = frames + (row * W + x0) * 3;
+        uint32_t w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = ((const uint32_t*)src)[k];        // 12 bytes; (row * W + x0) * 3 is a multiple of 4
+        float px[4][3];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) px[e / 3][e % 3] = (float)((w[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+        const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (px[fl ? 3 - j : j][c] / 255.0f - mean[c]) / sd[c];
+            *(f32x4*)(out + (((size_t)b * 3 + c) * T + t) * plane + (size_t)y * W + 4 * xq) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ token mean
 __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int D) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
@@ -556,6 +592,19 @@ extern "C" int unite_pseudo_label_select(const float* logits_full, const float* 
 extern "C" int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
     if (!qkv || !probs || B <= 0 || N <= 1 || N > 256 * CLS_KPT || H <= 0) return UNITE_EINVAL;
     hipLaunchKernelGGL(attn_cls_probs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, probs, N, H, scale);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_clip_u8_to_f32(const uint8_t* frames, float* out, const uint8_t* flip, const float* mean3, const float* std3, int32_t B,
+                                    int32_t T, int32_t H, int32_t W, void* stream) {
+    if (!frames || !out || !mean3 || !std3 || B <= 0 || T <= 0 || H <= 0 || W <= 0 || (W & 3) || (((uintptr_t)frames) & 3) ||
+        (((uintptr_t)out) & 15))
+        return UNITE_EINVAL;
+    const size_t n_quads = (size_t)B * T * H * (W / 4);
+    const size_t blocks = (n_quads + 255) / 256;
+    hipLaunchKernelGGL(clip_u8_to_f32_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, frames, out, flip,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], T, H, W, n_quads);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -178,6 +178,20 @@ def im2col_gather(video, token_index, cols, P: int):
     return cols
 
 
+def clip_u8_to_f32(frames, out, mean, std, flip=None):
+    """frames uint8 (B,T,H,W,3) -> out f32 (B,3,T,H,W), normalised (and flipped where flip[b] != 0)."""
+    lib = _lib.load()
+    _req(frames, torch.uint8, "frames")
+    _req(out, F32, "out")
+    B, T, H, W, Cc = frames.shape
+    assert Cc == 3 and frames.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, 3, T, H, W)
+    if flip is not None:
+        _req(flip, torch.uint8, "flip")
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(lib.unite_clip_u8_to_f32(_ptr(frames), _ptr(out), _ptr(flip), m3, s3, B, T, H, W, _stream()), "unite_clip_u8_to_f32")
+    return out
+
+
 def resize_bicubic(video, out):
     """(B,C,T,H,W) f32 -> out (B,C,T,OH,OW): per-plane bicubic resize, align_corners=False."""
     lib = _lib.load()
