@@ -15,6 +15,7 @@ when the finite-loss check (:447-449) also runs; the mask never visits the host.
 from __future__ import annotations
 
 import math
+import os
 import sys
 import time
 from typing import Iterable, Optional
@@ -32,6 +33,7 @@ class StepState:
         self.vis = None
         self.rows = None
         self.seed = 0
+        self.overlap_targets = os.environ.get("UNITE_OVERLAP_TARGETS", "1") != "0"
 
 
 def teacher_input(teacher_model, videos, clip_input_resolution):
@@ -70,7 +72,21 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
         state.mask = m8
         ops.mask_to_tokens(m8, state.vis, n_vis_frame, BT, N, vis_rows_cls=state.rows)
     M = B * n_vis
-    targets = teacher_model.visible_targets(state.rows, M)       # f32 [K*M, C], rows in (k, b, token) order
+    # The teacher's tail (last block on the visible rows, ln_post, proj, L2) is only needed by the loss: it runs on the teacher's
+    # side stream under the student's encoder forward.
+    trt = getattr(teacher_model, "module", teacher_model).runtime()
+    ready = None
+    if state.overlap_targets and videos.is_cuda:
+        main, side = torch.cuda.current_stream(), trt._side_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            targets = teacher_model.visible_targets(state.rows, M)       # f32 [K*M, C], rows in (k, b, token) order
+            ready = torch.cuda.Event()
+            ready.record(side)
+    else:
+        targets = teacher_model.visible_targets(state.rows, M)
     # which clips take part in the loss (:418-427).  Samples are independent in the student, so restricting the loss to a
     # slice of the batch equals running the student on that slice only.
     if clip_loss_data == 'mixed':
@@ -84,12 +100,15 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
     if hi <= lo:
         raise ValueError(f"clip_loss_data='{clip_loss_data}' selects no clip (no target loader?): the reference's loss is NaN here")
     if (lo, hi) != (0, B):
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+            ready = None
         K = targets.shape[0] // M
         targets = targets.view(K, B, n_vis, -1)[:, lo:hi].contiguous().view(K * (hi - lo) * n_vis, -1)
         videos_l = videos[lo:hi].contiguous()
         vis_l = (state.vis.view(B, n_vis)[lo:hi] - lo * T * N).contiguous().view(-1)
         return model.forward_loss(videos_l, vis_l, n_vis, targets)
-    return model.forward_loss(videos, state.vis, n_vis, targets)
+    return model.forward_loss(videos, state.vis, n_vis, targets, targets_ready=ready)
 
 
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_train_target: Optional[Iterable],

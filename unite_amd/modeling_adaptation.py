@@ -202,10 +202,12 @@ class AdaptationVisionTransformer(nn.Module):
             vis_tokens, n_vis = rt.tokens_from_mask(mask)
         return _StudentFn.apply(self, x, vis_tokens, n_vis, clip_only, rt.grad_anchor)
 
-    def forward_loss(self, x, vis_tokens, n_vis, targets):
+    def forward_loss(self, x, vis_tokens, n_vis, targets, targets_ready=None):
         """Fused stage-1 objective: mean(2 - 2 <decoder(x), targets>) over (K,B,n_vis) (run_stage1.py:431) without
-        materialising x_clip.  targets: f32 [K*B*n_vis, C] rows in (k, b, token) order, L2-normalised."""
+        materialising x_clip.  targets: f32 [K*B*n_vis, C] rows in (k, b, token) order, L2-normalised.  targets_ready: optional
+        event after which `targets` is valid (the teacher's tail may still be running on another stream during the encoder)."""
         rt = self.runtime()
+        rt.targets_ready = targets_ready
         return _StudentLossFn.apply(self, x, vis_tokens, n_vis, targets, rt.grad_anchor)
 
 
@@ -453,6 +455,10 @@ class _StudentLossFn(torch.autograd.Function):
         M, C, K = videos.shape[0] * n_vis, rt.C, len(rt.taps)
         loss_sum = rt.ws.get("loss.sum", (1,), F32)
         loss_sum.zero_()
+        ev = getattr(rt, "targets_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            rt.targets_ready = None
         tg = targets.view(K, M, C)
         for k in range(K):
             d = rt.dec[k]
