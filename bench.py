@@ -137,6 +137,7 @@ def main():
     if a.serial:
         student.runtime().runner.wgrad_stream = False
         teacher.runtime().two_streams = False
+        state.overlap_targets = False
     it = [0]
 
     def step():
@@ -176,6 +177,7 @@ def main():
         """side-stream weight gradients (student) and the two-stream teacher; off = every kernel alone on the GPU"""
         student.runtime().runner.wgrad_stream = on
         teacher.runtime().two_streams = on
+        state.overlap_targets = on
 
     roof = None
     if not a.no_roofline:
