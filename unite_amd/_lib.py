@@ -12,6 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libunite_hip.so")
+LIB_PATH = os.environ.get("UNITE_HIP_LIB", LIB_PATH)        # A/B runs of two builds of the library in one gpurun call
 
 c_p = C.c_void_p
 c_i = C.c_int32
