@@ -225,3 +225,40 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
     metric_logger.synchronize_between_processes()
     print(f"[{time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())}] Averaged stats:", metric_logger)
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def validation_one_epoch(data_loader, encoder, src_classifier, device, fp32=False, args=None, use_wandb=False, save_preds_path=None):
+    """run_stage3.py:714-787: the student encoder on ALL tokens, mean-pooled, through the source classifier; loss / top-1 / top-5."""
+    from .engine_for_finetuning import accuracy
+    criterion = torch.nn.CrossEntropyLoss()
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    header = 'Val:'
+    encoder.eval()
+    src_classifier.eval()
+    student = getattr(encoder, "module", encoder)
+    if getattr(args, "use_cls_token", False):
+        raise NotImplementedError("use_cls_token is not built")
+    rt = student.runtime()
+    W, b = src_classifier.weight.detach().float().contiguous(), src_classifier.bias.detach().float().contiguous()
+    for batch in metric_logger.log_every(data_loader, 10, 1, 0, len(data_loader), header):
+        videos = batch[0]
+        target = batch[2] if getattr(args, "return_aug_for_val", False) else batch[1]
+        videos = videos.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        B, T = videos.shape[0], videos.shape[2]
+        n = T * rt.frame_tokens
+        xv = rt.encode(videos, None, n, "s3val", False, save=False)          # encoder.norm(x) for every token, no activations kept
+        pooled = torch.empty(B, rt.D, dtype=F32, device=videos.device)
+        ops.token_mean_fwd(xv.view(B, n, rt.D), pooled)
+        class_logits = torch.empty(B, W.shape[0], dtype=F32, device=videos.device)
+        ops.linear_f32_fwd(pooled, W, b, class_logits)
+        loss = criterion(class_logits, target)
+        acc1, acc5 = accuracy(class_logits, target, topk=(1, 5))
+        metric_logger.update(loss=loss.item())
+        metric_logger.meters['acc1'].update(acc1.item(), n=B)
+        metric_logger.meters['acc5'].update(acc5.item(), n=B)
+    metric_logger.synchronize_between_processes()
+    print('* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}'
+          .format(top1=metric_logger.acc1, top5=metric_logger.acc5, losses=metric_logger.loss))
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
