@@ -150,6 +150,11 @@ int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, in
 int unite_im2col_gather(const float* video, const int32_t* token_index, void* cols, int32_t ld_cols,
                         int32_t n_rows, int32_t B, int32_t T, int32_t H, int32_t W, int32_t P, void* stream);
 
+/* Zero-shot CLIP similarities of utils.clip_infer (src/utils.py:55-68): out[b,c] = mean over the T frames of clip b of
+ * softmax_c(scale * <img[b*T+t,:], text[c,:]>), both operands L2-normalised f32, scale = 100, n_cls <= 256, C % 4 == 0. */
+int unite_clip_similarity(const float* img, const float* text, float* out, int32_t B, int32_t T, int32_t C, int32_t n_cls,
+                          float scale, void* stream);
+
 /* Decoded uint8 frames (B,T,H,W,3) -> the f32 (B,3,T,H,W) clip tensor the engines take: ((x / 255) - mean[c]) / std[c] with an
  * optional left-right flip per clip (flip: device uint8[B] or NULL).  Replaces the CPU-side GroupRandomHorizontalFlip + Stack +
  * ToTorchFormatTensor + GroupNormalize + view/transpose of src/datasets/transforms.py:68-96,209-245 and mae.py:218-219 (the

@@ -565,3 +565,34 @@ def clip_to_tensor(frames_u8: Tensor, mean: Sequence[float], std: Sequence[float
             t.sub_(m).div_(s)
         out.append(img.view((fr.shape[0], 3) + img.shape[-2:]).transpose(0, 1))
     return torch.stack(out)
+
+
+def clip_encode_image(sd: SD, frames: Tensor, cfg: TeacherCfg) -> Tensor:
+    """OpenAI CLIP ``VisionTransformer.forward`` (package `clip`, pinned as git+https://github.com/openai/CLIP.git in the reference's
+    environment.yaml:353; not vendored): conv1 -> [cls; patches] + pos -> ln_pre -> blocks -> ln_post(x[:, 0]) @ proj.  Same blocks as
+    teacher_forward (the reference's clip.py is derived from it).  frames (N,3,H,W) -> (N, output_dim), not normalised."""
+    W = cfg.width
+    cols = im2col(frames.unsqueeze(2), cfg.patch_size, 1)                       # (N, HW, 3*P*P)
+    x = cols @ sd["conv1.weight"].reshape(W, -1).t()
+    x = torch.cat([sd["class_embedding"].expand(x.shape[0], 1, W), x], dim=1) + sd["positional_embedding"]
+    x = layer_norm(x, sd["ln_pre.weight"], sd["ln_pre.bias"], cfg.ln_eps)
+    for i in range(cfg.layers):
+        p = f"transformer.resblocks.{i}."
+        h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], cfg.ln_eps)
+        x = x + mha(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"], sd[p + "attn.out_proj.weight"],
+                    sd[p + "attn.out_proj.bias"], cfg.heads)
+        h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], cfg.ln_eps)
+        x = x + F.linear(quick_gelu(F.linear(h, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"])),
+                         sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
+    return layer_norm(x[:, 0], sd["ln_post.weight"], sd["ln_post.bias"], cfg.ln_eps) @ sd["proj"]
+
+
+def clip_infer(sd: SD, videos: Tensor, text_features: Tensor, cfg: TeacherCfg) -> Tensor:
+    """src/utils.py:55-68: per-frame similarities (x100, soft-max over classes) averaged over the frames of each clip."""
+    B, C, T, H, Wd = videos.shape
+    images = videos.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, Wd)
+    f = clip_encode_image(sd, images, cfg)
+    f = f / f.norm(dim=-1, keepdim=True)
+    t = text_features / text_features.norm(dim=-1, keepdim=True)
+    sim = (100 * f @ t.t()).softmax(dim=-1)
+    return sim.view(B, T, -1).mean(dim=1)

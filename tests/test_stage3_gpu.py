@@ -168,3 +168,39 @@ def test_stage3_engine_epoch_updates_encoder_only():
             moved += delta > 0
     assert moved >= len(before) - 4 - 2
     assert torch.equal(cls.weight.detach(), cls_before)           # A-8: the classifier is used, never optimised
+
+
+def test_zero_shot_clip_image_side_vs_oracle():
+    """utils.clip_infer (src/utils.py:55-68) with the image tower on the HIP kernels: frame embeddings against the oracle's
+    restatement of OpenAI CLIP's encode_image (cosine >= 0.999), the similarity kernel against torch on identical inputs (1e-5),
+    and the end-to-end probabilities (the x100 temperature turns a 1e-3 cosine error into ~0.1 in the logits: abs 0.08)."""
+    from unite_amd import ops, utils
+    from unite_amd.clip import VisionTransformer
+    from tests.shapes import TINY_T
+    t = VisionTransformer(input_resolution=32, patch_size=16, width=128, layers=3, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[1, 2])
+    sd = fill_state_dict(teacher_shapes(TINY_T), 71)
+    t.load_state_dict(sd)
+    t = t.to(DEV).eval()
+    vid = make_videos(3, 2, 32, 32, seed=72)
+    g = torch.Generator().manual_seed(73)
+    text = torch.randn(5, 64, generator=g)
+    frames = vid.permute(0, 2, 1, 3, 4).reshape(6, 3, 32, 32)
+    ref_f = O.clip_encode_image(sd, frames, TINY_T)
+    ref_f = ref_f / ref_f.norm(dim=-1, keepdim=True)
+    f = t.encode_image(vid.to(DEV)).clone()
+    assert f.shape == (6, 64)
+    assert torch.nn.functional.cosine_similarity(f.cpu(), ref_f, dim=-1).min().item() >= 0.999
+    tn = (text / text.norm(dim=-1, keepdim=True)).to(DEV)
+    out = torch.empty(3, 5, device=DEV)
+    ops.clip_similarity(f, tn, out, 2, 100.0)
+    want = (100 * f @ tn.t()).softmax(-1).view(3, 2, 5).mean(1)
+    torch.testing.assert_close(out, want, atol=1e-5, rtol=1e-5)
+    probs = utils.clip_infer(t, vid.to(DEV), text.to(DEV)).cpu()
+    ref = O.clip_infer(sd, vid, text, TINY_T)
+    assert torch.allclose(probs.sum(-1), torch.ones(3), atol=1e-5)
+    torch.testing.assert_close(probs, ref, atol=8e-2, rtol=0)
+    # the taps / attention of the mask-teacher role are untouched by the zero-shot pass
+    feats, attn = t(vid.to(DEV))
+    rf, ra = O.teacher_forward(sd, vid, TINY_T, return_attn=True)
+    assert torch.nn.functional.cosine_similarity(feats.cpu().flatten(0, -2), rf.flatten(0, -2), dim=-1).min().item() >= 0.999

@@ -113,6 +113,11 @@ class VisionTransformer(nn.Module):
         return self.runtime().forward_taps(x)
 
     @torch.no_grad()
+    def encode_image(self, videos):
+        """(B,3,T,H,W) -> (B*T, output_dim) L2-normalised frame embeddings (zero-shot CLIP image side, src/utils.py:55-61)."""
+        return self.runtime().cls_features(videos)
+
+    @torch.no_grad()
     def visible_targets(self, vis_rows_cls, n_rows):
         """ln_post + proj + L2-norm of the taps at the listed rows only -> f32 [K*n_rows, C] (run_stage1.py:389-397)."""
         return self.runtime().targets(vis_rows_cls, n_rows)
@@ -258,6 +263,19 @@ class _TeacherRuntime:
         attn = ws.get("attn", (BT, HW), F32)
         ops.attn_cls_probs(qkv, attn, BT, L, H, scale)          # qkv still holds the last block's projections
         return attn
+
+    def cls_features(self, videos: torch.Tensor) -> torch.Tensor:
+        """L2-normalised image embeddings of every frame, (B*T, C): OpenAI CLIP's ``encode_image`` (ln_post(x[:, 0]) @ proj) as
+        utils.clip_infer uses it (src/utils.py:55-61) -- this tower with the last block evaluated on the CLS rows only."""
+        taps = self.taps
+        self.taps = [self.layers - 1]
+        try:
+            self.forward_taps(videos)
+            BT = videos.shape[0] * videos.shape[2]
+            rows = (torch.arange(BT, dtype=torch.int32, device=self.dev) * self.L).contiguous()
+            return self.targets(rows, BT)
+        finally:
+            self.taps = taps
 
     def _last_block_rows(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
         """out_proj + MLP of the last block on the listed token rows only -> x_out f32 [n_rows, D] (same arithmetic per row)."""

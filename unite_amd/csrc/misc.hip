@@ -377,6 +377,41 @@ __global__ __launch_bounds__(256) void clip_u8_to_f32_kernel(const uint8_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------ zero-shot similarities (utils.py:55-68)
+// out[b, c] = mean_t softmax_c( scale * <img[b*T + t, :], text[c, :]> ).  One workgroup per clip; thread c owns class c (n_cls <= 256).
+__global__ __launch_bounds__(256) void clip_similarity_kernel(const float* __restrict__ img, const float* __restrict__ text, float* __restrict__ out,
+                                                              int T, int C, int n_cls, float scale) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* f = img + (size_t)(b * T + t) * C;
+        float logit = -INFINITY;
+        if (c < n_cls) {
+            const float* w = text + (size_t)c * C;
+            float d = 0.f;
+            for (int k = 0; k < C; k += 4) {
+                const f32x4 a = *(const f32x4*)(f + k), bb = *(const f32x4*)(w + k);
+                d += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+            }
+            logit = scale * d;
+        }
+        float m = wave_max(logit);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        const float e = c < n_cls ? __expf(logit - m) : 0.f;
+        float ssum = wave_sum(e);
+        if (lane == 0) red[wave] = ssum;
+        __syncthreads();
+        ssum = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        acc += e / ssum;
+    }
+    if (c < n_cls) out[(size_t)b * n_cls + c] = acc / (float)T;
+}
+
 // ------------------------------------------------------------------------------------ token mean
 __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int D) {
     const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
@@ -592,6 +627,14 @@ extern "C" int unite_pseudo_label_select(const float* logits_full, const float* 
 extern "C" int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale, void* stream) {
     if (!qkv || !probs || B <= 0 || N <= 1 || N > 256 * CLS_KPT || H <= 0) return UNITE_EINVAL;
     hipLaunchKernelGGL(attn_cls_probs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, probs, N, H, scale);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_clip_similarity(const float* img, const float* text, float* out, int32_t B, int32_t T, int32_t C, int32_t n_cls,
+                                     float scale, void* stream) {
+    if (!img || !text || !out || B <= 0 || T <= 0 || C <= 0 || (C & 3) || n_cls <= 0 || n_cls > 256) return UNITE_EINVAL;
+    hipLaunchKernelGGL(clip_similarity_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, img, text, out, T, C, n_cls, scale);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

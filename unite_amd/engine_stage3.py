@@ -12,8 +12,9 @@ Per step (reference lines in brackets):
 Kept quirks: ``src_classifier`` is used but never optimised; only the LAST committee member's
 logits enter the loss (the first member's pass therefore runs without saving activations -- samples are independent, its
 gradient in the reference's batched pass is exactly zero); the pseudo-label is always the student's own prediction;
-``global_threshold`` is 0.5.  The zero-shot CLIP probabilities of the clip_* strategies (OpenAI CLIP image + text towers,
-utils.clip_infer) are outside the built path: they are supplied by ``clip_probs_fn(videos_t) -> (B_t, C)`` .
+``global_threshold`` is 0.5.  The zero-shot CLIP probabilities of the clip_* strategies come from ``clip_probs_fn(videos_t) -> (B_t, C)``:
+``functools.partial(utils.clip_infer, clip_model, text_features=...)`` runs the CLIP image tower on the HIP kernels (unite_amd.clip
+VisionTransformer.encode_image + unite_clip_similarity); the class text embeddings are the caller's (tokenizer / text tower: out of scope).
 """
 from __future__ import annotations
 

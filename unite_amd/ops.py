@@ -178,6 +178,15 @@ def im2col_gather(video, token_index, cols, P: int):
     return cols
 
 
+def clip_similarity(img, text, out, T: int, scale: float = 100.0):
+    lib = _lib.load()
+    _req(img, F32, "img"); _req(text, F32, "text"); _req(out, F32, "out")
+    B, n_cls = out.shape
+    assert img.shape[0] == B * T and img.shape[1] == text.shape[1] and text.shape[0] == n_cls and img.is_contiguous() and text.is_contiguous()
+    _lib.check(lib.unite_clip_similarity(_ptr(img), _ptr(text), _ptr(out), B, T, img.shape[1], n_cls, scale, _stream()), "unite_clip_similarity")
+    return out
+
+
 def clip_u8_to_f32(frames, out, mean, std, flip=None):
     """frames uint8 (B,T,H,W,3) -> out f32 (B,3,T,H,W), normalised (and flipped where flip[b] != 0)."""
     lib = _lib.load()

@@ -84,6 +84,19 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
     return total.sqrt()[0]
 
 
+# ----------------------------------------------------------------------------- zero-shot CLIP similarities (utils.py:55-68)
+def clip_infer(model, videos, text_features):
+    """reference utils.clip_infer: per-frame image embeddings (here: unite_amd.clip.VisionTransformer.encode_image, i.e. the frozen
+    CLIP image tower on the HIP kernels), cosine similarity x 100 against the class text embeddings, soft-max, mean over the frames.
+    ``text_features`` (n_classes, C) come from the caller: OpenAI's tokenizer / text tower are not part of this build."""
+    B, T = videos.shape[0], videos.shape[2]
+    img = model.encode_image(videos)
+    text = text_features.float()
+    text = (text / text.norm(dim=-1, keepdim=True)).contiguous()           # (the reference normalises the caller's tensor in place)
+    out = torch.empty(B, text.shape[0], dtype=torch.float32, device=videos.device)
+    return ops.clip_similarity(img, text, out, T, 100.0)
+
+
 # ----------------------------------------------------------------------------- schedules (utils.py:646-686)
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
     warmup_schedule = np.array([])
