@@ -316,6 +316,41 @@ def test_stage1_vitl_cfg5_vs_oracle():
     assert worst <= 8e-2, worst          # 24 layers of bf16 operands; the per-tensor bound for ViT-B's 12 is 5e-2
 
 
+def test_streams_on_off_bit_identical_full_size():
+    """BASELINE config-2 shapes at B = 8: the step with every side stream on (two-stream teacher, overlapped target tail, weight
+    gradients on their own stream) produces bit-identical gradients to the same step on one stream -- the arithmetic is the same
+    and deterministic, so any difference would be a missing event / buffer-reuse race."""
+    import unite_amd
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    student = unite_amd.create_model("adaptation_umt_base_patch16_224", pretrained=False, drop_path_rate=0.0, num_frames=8,
+                                     tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+                                     clip_return_layers=[6, 7, 8, 9, 10, 11], use_cls_token=False, use_learnable_pos_emb=False,
+                                     use_checkpoint=False, checkpoint_num=0, clip_norm_type='l2', clip_student_return_interval=1,
+                                     drop_block_rate=None)
+    teacher = unite_amd.clip.clip_b16(pretrained=False, return_attn=True, clip_return_layers=[6, 7, 8, 9, 10, 11])
+    student.load_state_dict(fill_state_dict(student_shapes(O.StudentCfg()), 3))
+    teacher.load_state_dict(fill_state_dict(teacher_shapes(O.TeacherCfg()), 4))
+    student, teacher = student.to(DEV).train(), teacher.to(DEV)
+    B = 8
+    vid = make_videos(B, 8, 224, 224, 5).to(DEV)
+    imp = make_importance(B * 8, 196, 6).to(DEV)
+    rt, trt = student.runtime(), teacher.runtime()
+    grads, attns = [], []
+    for on in (False, True, True):                      # the concurrent form twice: steady-state buffer reuse included
+        rt.runner.wgrad_stream, trt.two_streams = on, on
+        st = StepState()
+        st.overlap_targets = on
+        rt.fp.accumulate = False
+        loss = stage1_step(student, teacher, vid, B, 0.8, 'attention', None, 'mixed', st, importance=imp)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(rt.fp.grad.clone())
+        attns.append(trt.ws.bufs["attn"].clone())
+        assert torch.isfinite(loss).item() and 1.0 < loss.item() < 2.5
+    assert torch.equal(attns[0], attns[1]) and torch.equal(attns[1], attns[2])
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
+
+
 def test_train_one_epoch_synthetic():
     """The drop-in engine on a synthetic loader: attention-guided masks, 6 steps, loss goes down, meters come back."""
     import unite_amd
