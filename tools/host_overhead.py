@@ -1,0 +1,32 @@
+import os, sys, time, torch
+sys.path.insert(0, '.')
+sys.argv = ['bench.py']
+import bench
+import unite_amd
+from unite_amd.engine_stage1 import StepState, stage1_step
+from unite_amd.optim_factory import create_optimizer
+from unite_amd.utils import NativeScalerWithGradNormCount
+from types import SimpleNamespace
+dev = torch.device('cuda')
+B, T = int(os.environ.get("B", 32)), 8
+student = unite_amd.create_model("adaptation_umt_base_patch16_224", pretrained=False, drop_path_rate=0.1, drop_block_rate=None, use_learnable_pos_emb=False,
+    use_checkpoint=False, checkpoint_num=0, clip_decoder_embed_dim=768, clip_output_dim=512, clip_norm_type='l2', num_frames=T,
+    tubelet_size=1, clip_return_layers=[6, 7, 8, 9, 10, 11], clip_student_return_interval=1, use_cls_token=False).to(dev).train()
+teacher = unite_amd.clip.clip_b16(pretrained=False, return_attn=True, clip_return_layers=[6, 7, 8, 9, 10, 11]).to(dev)
+args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1.5e-4 * B / 256, opt_eps=1e-8, opt_betas=[0.9, 0.95])
+opt = create_optimizer(args, student, skip_list=student.no_weight_decay())
+scaler = NativeScalerWithGradNormCount()
+videos = torch.randn(B, 3, T, 224, 224, device=dev)
+state = StepState()
+def step():
+    loss = stage1_step(student, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
+    opt.zero_grad()
+    return loss, scaler(loss, opt, clip_grad=None, parameters=None)
+for _ in range(5): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"enqueue {1e3*(t1-t0)/20:.2f} ms/step; total {1e3*(t2-t0)/20:.2f} ms/step")

@@ -413,12 +413,38 @@ __global__ __launch_bounds__(256) void clip_similarity_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------ token mean
+// one workgroup per (clip, 64 columns): thread (g, q) = (tid >> 4, tid & 15) sums tokens g, g + 16, ... of columns 4q .. 4q+3
+// (16-byte loads, 256 B per 16 lanes), then the 16 token groups are added in a fixed order through LDS.  (The first version
+// walked all N tokens in one thread per column: 1.1 ms for 16 x 3136 x 768.)
 __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int D) {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += x[((size_t)b * N + n) * D + c];
-    out[(size_t)b * D + c] = a / (float)N;
+    __shared__ f32x4 red[16][16];
+    const int b = blockIdx.y, q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * q;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+        const float* p = x + (size_t)b * N * D + c;
+        int n = g;
+        for (; n + 48 < N; n += 64) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p + (size_t)(n + 16 * u) * D);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a = (f32x4){a[0] + v[u][0], a[1] + v[u][1], a[2] + v[u][2], a[3] + v[u][3]};
+        }
+        for (; n < N; n += 16) {
+            const f32x4 v = *(const f32x4*)(p + (size_t)n * D);
+            a = (f32x4){a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3]};
+        }
+    }
+    red[g][q] = a;
+    __syncthreads();
+    if (g == 0 && c < D) {
+        f32x4 t = red[0][q];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t = (f32x4){t[0] + red[i][q][0], t[1] + red[i][q][1], t[2] + red[i][q][2], t[3] + red[i][q][3]};
+        const float inv = 1.0f / (float)N;
+        *(f32x4*)(out + (size_t)b * D + c) = (f32x4){t[0] * inv, t[1] * inv, t[2] * inv, t[3] * inv};
+    }
 }
 // ------------------------------------------------------------------------------------ small fp32 linear (classifier head)
 // y[b,c] = <x[b,:], W[c,:]> + bias[c]   -- B <= a few dozen rows, C = number of classes: one workgroup per row
@@ -662,8 +688,8 @@ extern "C" int unite_resize_bicubic(const float* src, float* dst, int32_t planes
 }
 
 extern "C" int unite_token_mean_fwd(const float* x, float* out, int32_t B, int32_t N, int32_t D, void* stream) {
-    if (!x || !out || B <= 0 || N <= 0 || D <= 0) return UNITE_EINVAL;
-    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, out, N, D);
+    if (!x || !out || B <= 0 || N <= 0 || D <= 0 || (D & 3)) return UNITE_EINVAL;
+    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, out, N, D);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -6,7 +6,13 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK_BWD = 16;    // 4 waves x 4 rows: dgamma/dbeta partial sums per workgroup
+// rows per workgroup of the LayerNorm / decoder-tail backward (4 waves, one row each per iteration): 16 up to 16 k rows, then
+// grown so that at most ~1024 partial-sum rows reach the second-stage reduction (50 176 tokens of stage 2: 52 rows per workgroup,
+// 965 partials instead of 3 136 -- the reduction over those took 189 us per call)
+__host__ __device__ inline int bwd_rows_per_block(int M) {
+    const int r = (M + 1023) / 1024;
+    return r <= 16 ? 16 : (r + 3) / 4 * 4;
+}
 
 template <int NV>
 __device__ __forceinline__ void load_row(const float* row, int D, int lane, f32x4 (&v)[NV]) {
@@ -94,8 +100,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         gam[i] = (c < D) ? *(const f32x4*)(gamma + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         dg[i] = db[i] = ds[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
-        const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
+    const int rpb = bwd_rows_per_block(M);
+    for (int r = 0; r < rpb / 4; ++r) {
+        const int row = blockIdx.x * rpb + r * 4 + wave;
         if (row >= M) break;
         f32x4 xv[NV], dyv[NV];
         load_row<NV>(x + (size_t)row * ldx, D, lane, xv);
@@ -278,8 +285,9 @@ __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __re
         bet[i] = (c < C) ? *(const f32x4*)(beta + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         dg[i] = db[i] = ds[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int r = 0; r < ROWS_PER_BLOCK_BWD / 4; ++r) {
-        const int row = blockIdx.x * ROWS_PER_BLOCK_BWD + r * 4 + wave;
+    const int rpb = bwd_rows_per_block(M);
+    for (int r = 0; r < rpb / 4; ++r) {
+        const int row = blockIdx.x * rpb + r * 4 + wave;
         if (row >= M) break;
         f32x4 v[NV], u[NV], dov[NV];
         load_row<NV>(y + (size_t)row * C, C, lane, v);
@@ -445,7 +453,7 @@ extern "C" int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* r
 }
 
 extern "C" size_t unite_layernorm_bwd_workspace(int32_t M, int32_t D) {
-    const size_t nb = (size_t)(M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    const size_t nb = (size_t)(M + bwd_rows_per_block(M) - 1) / bwd_rows_per_block(M);
     return nb * 3 * (size_t)D * sizeof(float);
 }
 
@@ -456,7 +464,7 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     if (!dy || !x || !mean || !rstd || !gamma || !workspace || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
     if (row_scale && rows_per_scale <= 0) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    const int nb = (M + bwd_rows_per_block(M) - 1) / bwd_rows_per_block(M);
     DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma,
                                       dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
     UNITE_LAUNCH_CHECK();
@@ -484,7 +492,7 @@ extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const 
                                       float* dysum, int32_t accumulate, void* workspace, int32_t M, int32_t C, void* stream) {
     if (!y || !gamma || !beta || !dy_bf16 || !workspace || (!tgt && !dout) || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (M + ROWS_PER_BLOCK_BWD - 1) / ROWS_PER_BLOCK_BWD;
+    const int nb = (M + bwd_rows_per_block(M) - 1) / bwd_rows_per_block(M);
     DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, y, gamma, beta, eps, tgt, loss_scale,
                                       loss_scale_dev, dout, dy_bf16, (float*)workspace, M, C));
     UNITE_LAUNCH_CHECK();
