@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const float* __re
                                                                float* __restrict__ out, float* __restrict__ loss_sum, int M, int C) {
     __shared__ float wl[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
     float l = 0.f;
-    if (row < M) {
+    // grid-stride over rows: one atomicAdd per WORKGROUP at the end (one per 4 rows serialised 2 560 atomics on one address:
+    // 39 us per call for 42 MB of traffic)
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         f32x4 v[NV];
         load_row<NV>(y + (size_t)row * C, C, lane, v);
         float mean, rstd;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void decoder_tail_fwd_kernel(const float* __re
                 if (c < C) *(f32x4*)(out + (size_t)row * C + c) = (f32x4){v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
             }
         }
-        l = 2.0f - 2.0f * dt * inv;
+        l += 2.0f - 2.0f * dt * inv;
     }
     if (loss_sum && tgt) {
         if (lane == 0) wl[wave] = l;
@@ -481,7 +482,8 @@ extern "C" int unite_decoder_tail_fwd(const float* y, const float* gamma, const 
                                       float* loss_sum, int32_t M, int32_t C, void* stream) {
     if (!y || !gamma || !beta || M <= 0 || !dim_ok(C)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, y, gamma, beta, eps, tgt, out,
+    const int blocks = (M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024;
+    DISPATCH_NV(C, hipLaunchKernelGGL((decoder_tail_fwd_kernel<NV>), dim3(blocks), dim3(256), 0, s, y, gamma, beta, eps, tgt, out,
                                       loss_sum, M, C));
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
