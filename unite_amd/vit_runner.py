@@ -129,7 +129,9 @@ class ViTRunner:
         """(depth, 2, B) f32 multipliers floor(keep + U)/keep (timm drop_path as used at modeling_finetune.py:50), or None."""
         if not training or max(self.dp_rates) == 0.0:
             return None
-        keep = 1.0 - torch.tensor(self.dp_rates, dtype=F32, device=self.fp.device).view(-1, 1, 1)
+        if getattr(self, "_keep", None) is None:        # uploaded once: a host -> device copy here would block the host every step
+            self._keep = (1.0 - torch.tensor(self.dp_rates, dtype=F32)).view(-1, 1, 1).to(self.fp.device)
+        keep = self._keep
         u = torch.rand(self.depth, 2, B, dtype=F32, device=self.fp.device)
         return torch.floor(keep + u) / keep
 
