@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int r = 0; r < rpb / 4; ++r) {
         const int row = blockIdx.x * rpb + r * 4 + wave;
         if (row >= M) break;
-        f32x4 xv[NV], dyv[NV];
+        f32x4 xv[NV], dyv[NV], resv[NV];
         load_row<NV>(x + (size_t)row * ldx, D, lane, xv);
+        if (dx_residual) load_row<NV>(dx_residual + (size_t)row * D, D, lane, resv);      // with the other loads: one memory round trip per row
         if (dy_f32) load_row<NV>((const float*)dy + (size_t)row * D, D, lane, dyv);
         else {
 #pragma unroll
@@ -143,9 +144,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gam[i][e] * dyv[i][e] - s1 - xv[i][e] * s2);
                 if (dx_residual) {
-                    const f32x4 a = *(const f32x4*)(dx_residual + (size_t)row * D + c);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += a[e];
+                    for (int e = 0; e < 4; ++e) o[e] += resv[i][e];
                 }
                 if (dx_out) *(f32x4*)(dx_out + (size_t)row * D + c) = o;
                 if (dx_bf16) {
