@@ -133,6 +133,14 @@ int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N,
  * from qkv and lse.  delta (f32 [B,H,N]) is workspace. */
 int unite_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                    void* dqkv, int32_t B, int32_t N, int32_t H, float scale, void* stream);
+/* Frozen-teacher block front half in one kernel (clip.py:38,48-53 under no_grad): for every (frame, head)
+ *   [q | k | v] = h_frame [L x D] . in_proj_weight[head rows]^T + in_proj_bias  (bf16 operands, f32 accumulation, bf16 results)
+ *   out_frame[:, head] = softmax(q k^T * scale) v
+ * without writing qkv to memory.  h: bf16 [BT*L, D] (the LayerNorm output), w_in: bf16 [3D, D], b_in: f32 [3D], out: bf16 [BT*L, D].
+ * 192 < L <= 224 (197 = 14 x 14 patches + CLS), D = 64 H.  Same arithmetic as unite_gemm_bf16 (bias) + unite_attn_fwd. */
+int unite_teacher_qkv_attn(const void* h, const void* w_in, const float* b_in, void* out, int32_t BT, int32_t L, int32_t H,
+                           int32_t D, float scale, void* stream);
+
 /* Head-averaged softmax probabilities of query row 0 (CLS) over key columns 1..N-1:
  * probs f32 [B, N-1].  Replaces need_weights=True + attn[:,0,1:] (clip.py:51,95-96,183). */
 int unite_attn_cls_probs(const void* qkv, float* probs, int32_t B, int32_t N, int32_t H, float scale,

@@ -322,6 +322,27 @@ def test_attention_softmax_spike(ops):
     torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1)])
+def test_teacher_fused_qkv_attention_matches_unfused(ops, BT, L, H):
+    """unite_teacher_qkv_attn (projection + attention in one workgroup per frame and head, qkv never written) against the two
+    kernels it replaces on the same inputs: same f32 accumulation order, same bf16 roundings -> identical bits expected; the
+    assertion allows one bf16 ulp on O(1) outputs for a different MFMA operand order."""
+    D = H * 64
+    hx = bf(rnd(BT * L, D, seed=L + H)).to(DEV)
+    w = bf(rnd(3 * D, D, seed=7, scale=D ** -0.5)).to(DEV)
+    b = rnd(3 * D, seed=8, scale=0.2).to(DEV)
+    qkv = torch.empty(BT * L, 3 * D, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(hx, w, qkv, bias=b)
+    o_ref = torch.empty(BT * L, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(BT, H, L, device=DEV)
+    ops.attn_fwd(qkv, o_ref, lse, BT, L, H, 0.125)
+    o = torch.full((BT * L, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.teacher_qkv_attn(hx, w, b, o, BT, L, H, 0.125)
+    assert torch.isfinite(o.float()).all()
+    torch.testing.assert_close(o.float(), o_ref.float(), atol=8e-3, rtol=8e-3)
+    assert (o != o_ref).float().mean().item() < 0.02          # in practice bit-identical almost everywhere
+
+
 @pytest.mark.parametrize("N,H", [(197, 12), (257, 16), (577, 4), (5, 2)])
 def test_attn_cls_probs(ops, N, H):
     B = 5

@@ -57,6 +57,7 @@ SIGNATURES = {
     "unite_attn_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "unite_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "unite_attn_cls_probs": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "unite_teacher_qkv_attn": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "unite_clip_similarity": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "unite_clip_u8_to_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_resize_bicubic": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

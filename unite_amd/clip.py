@@ -162,6 +162,7 @@ class _TeacherRuntime:
                 w_pr=fp.w16(b + "mlp.c_proj.weight"), b_pr=P(b + "mlp.c_proj.bias")))
         self._rows_cache = {}
         self.two_streams = os.environ.get("UNITE_TEACHER_STREAMS", "2") != "1"
+        self.fused_qkv = os.environ.get("UNITE_TEACHER_FUSED", "1") != "0" and 192 < self.L <= 224
         self._side = None
 
     def _side_stream(self):
@@ -221,7 +222,11 @@ class _TeacherRuntime:
             for i in range(self.layers):
                 w = self.blk[i]
                 ops.layernorm_fwd(xs, w["ln1"][0], w["ln1"][1], self.eps, h[r0:r1])
-                ops.gemm(h[r0:r1], w["w_in"], qkv[r0:r1], bias=w["b_in"])
+                if i != last and self.fused_qkv:
+                    # projection + attention of a (frame, head) in one workgroup: qkv never goes to memory (464 MB per block)
+                    ops.teacher_qkv_attn(h[r0:r1], w["w_in"], w["b_in"], o[r0:r1], nf, L, H, scale)
+                else:
+                    ops.gemm(h[r0:r1], w["w_in"], qkv[r0:r1], bias=w["b_in"])
                 if i == last:
                     # Only the CLS attention row of the last block is needed for every token (the mask weights, clip.py:95-96,183).
                     # If the block is a tap, the rest of it (out_proj, MLP) runs in targets() on the rows whose features are used
@@ -229,7 +234,8 @@ class _TeacherRuntime:
                     if pruned_tap:
                         ops.attn_fwd(qkv[r0:r1], o[r0:r1], lse[f0:f1], nf, L, H, scale)
                     return xs
-                ops.attn_fwd(qkv[r0:r1], o[r0:r1], lse[f0:f1], nf, L, H, scale)
+                if not self.fused_qkv:
+                    ops.attn_fwd(qkv[r0:r1], o[r0:r1], lse[f0:f1], nf, L, H, scale)
                 ops.gemm(o[r0:r1], w["w_out"], x1[r0:r1], bias=w["b_out"], residual=xs)
                 ops.layernorm_fwd(x1[r0:r1], w["ln2"][0], w["ln2"][1], self.eps, h[r0:r1])
                 ops.gemm(h[r0:r1], w["w_fc"], a[r0:r1], bias=w["b_fc"], act=ops.ACT_QUICKGELU)

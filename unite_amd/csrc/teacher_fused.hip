@@ -1,0 +1,166 @@
+// Fused QKV projection + attention of ONE (frame, head) per workgroup for the frozen CLIP teacher (clip.py:34-64, forward only).
+//
+// Unfused, every teacher block writes qkv [B*T*197, 3*D] bf16 (232 MB for CLIP-B/16 at B*T = 256) and the attention kernel reads
+// it back as 128-byte row slices at a 4.6-KB stride: 464 MB of HBM traffic per block plus the projection GEMM's epilogue.  Here
+// the workgroup computes its head's  [197 x 192] = LN(x)_frame [197 x D] . W_head^T  (q | k | v, 64 columns each) with MFMAs
+// from LDS-DMA-staged K-tiles (3-deep ring of 52 KiB: 224 activation rows + 192 weight rows of 64 k), adds the bias, drops the
+// bf16 q, k, v into LDS images and runs the exact-softmax attention of attention.hip on them; only O [197 x 64] leaves the CU.
+// The MFMAs are issued with the operands swapped (weights as A, activations as B): lane (G, c16) then holds four CONSECUTIVE
+// output columns of row c16, which leave as one packed 8-byte LDS store.
+// Arithmetic is that of the unfused path (f32 accumulation over k in the same order, + bias, round to bf16, same attention code).
+#include "attn_common.h"
+
+namespace {
+
+constexpr int FQ_MROWS = 224, FQ_NT16 = 14;             // activation rows per frame (197 valid for a 14 x 14 grid + CLS), key tiles
+constexpr int FQ_A_BYTES = FQ_MROWS * 128, FQ_B_BYTES = 192 * 128, FQ_STAGE = FQ_A_BYTES + FQ_B_BYTES;      // 28 + 24 = 52 KiB
+constexpr int FQ_LDS = 3 * FQ_STAGE;                    // 156 KiB ring; the q / k / v images (84 KiB) reuse it afterwards
+
+__global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t* __restrict__ hin, const uint16_t* __restrict__ w_in,
+                                                                  const float* __restrict__ b_in, uint16_t* __restrict__ out, int L, int H,
+                                                                  int D, float scale, uint32_t h_bytes, uint32_t w_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, G = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order (workgroups b, b + 8, ... share an XCD): each XCD gets a contiguous range of (frame, head) units, so the 12
+    // heads of a frame read its activation rows from one L2 instead of eight
+    const int nwg = (int)gridDim.x, bid = blockIdx.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int unit = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int frame = unit / H, h = unit % H;
+    const int wm = wave >> 2, wn = wave & 3;               // 8 waves: m-tiles wm*7 .. +7 (of 14), n-tiles wn*3 .. +3 (of 12)
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hin, 0, (int)h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)w_in, 0, (int)w_bytes, 0x00020000);
+    const int nk = D / 64;
+
+    // one K-tile: 224 activation rows (rows >= L read as zero; 28 pieces of 1 KiB: 7 per wave of waves 0-3) + the head's 3 x 64
+    // weight rows (24 pieces: 6 per wave of waves 4-7)
+    auto stage = [&](int t) {
+        char* buf = smem + (t % 3) * FQ_STAGE;
+        if (wave < 4) stage_rows(rsH, buf, FQ_MROWS, L, (uint32_t)(frame * L) * D + t * 64, D, wave, 4, lane);
+        else {
+#pragma unroll
+            for (int which = 0; which < 3; ++which)
+                stage_rows(rsW, buf + FQ_A_BYTES + which * 64 * 128, 64, 64, (uint32_t)(which * D + h * 64) * D + t * 64, D, wave - 4, 4, lane);
+        }
+    };
+    stage(0);
+    if (nk > 1) stage(1);
+
+    f32x4 acc[7][3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K-tile t landed; t + 1 may still be in flight
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();                                                        // ... for every wave; all are done with K-tile t - 1
+        if (t + 2 < nk) stage(t + 2);
+        const char* At = smem + (t % 3) * FQ_STAGE;
+        const char* Bt = At + FQ_A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xa[7], wb[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) xa[i] = row_frag(At, (wm * 7 + i) * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wb[j] = row_frag(Bt, (wn * 3 + j) * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);      // C^T: rows = output columns
+        }
+    }
+    __syncthreads();                                       // the ring is free: q | k | v images [224][64] bf16 go to its start
+
+    // ---- bias, bf16, LDS images (attention.hip layout: 128-B rows, 32-B chunk c at c ^ ((row >> 1) & 3))
+    char* const Qs = smem;
+    char* const Ks = smem + FQ_MROWS * 128;
+    char* const Vs = smem + 2 * FQ_MROWS * 128;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int nt = wn * 3 + j, which = nt >> 2, dchunk = nt & 3;
+        const f32x4 bias = *(const f32x4*)(b_in + which * D + h * 64 + dchunk * 16 + 4 * G);
+        char* img = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int row = (wm * 7 + i) * 16 + c;
+            const f32x4 v = acc[i][j];
+            *(u32x2*)(img + row_addr(row, dchunk * 2 + (G >> 1)) + (G & 1) * 8) =
+                (u32x2){pack_bf16x2(v[0] + bias[0], v[1] + bias[1]), pack_bf16x2(v[2] + bias[2], v[3] + bias[3])};
+        }
+    }
+    __syncthreads();
+
+    // ---- attention over the LDS-resident head (attention.hip's forward with Q from LDS as well; no LSE: the teacher has no backward)
+    constexpr int NT16 = FQ_NT16;
+    const float sl2 = scale * LOG2E;
+    const int nqt = (L + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 8) {
+        const int q = qt * 16 + c;
+        const bf16x8 qf0 = row_frag(Qs, qt * 16, 0, lane), qf1 = row_frag(Qs, qt * 16, 1, lane);
+        f32x4 st[NT16];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT16; ++kt) {
+            f32x4 s = mfma16(row_frag(Ks, kt * 16, 0, lane), qf0, (f32x4){0.f, 0.f, 0.f, 0.f});
+            s = mfma16(row_frag(Ks, kt * 16, 1, lane), qf1, s);
+            if (kt >= NT16 - 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * G + r >= L) s[r] = -INFINITY;
+            }
+            m = max3(max3(m, s[0], s[1]), s[2], s[3]);
+            st[kt] = s;
+        }
+        m = group_max(m);
+        const float ml2 = m * sl2;
+        float sum4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], sl2, -ml2));
+                st[kt][r] = p;
+                sum4[r] += p;
+            }
+        const float sum = group_sum((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT16 / 2; ++kk) {
+            const bf16x8 pf = pack_pair(st[2 * kk], st[2 * kk + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(Vs, kk * 32, dt, lane), pf, o[dt]);
+        }
+        if (q < L) {
+            const float inv = 1.0f / sum;
+            uint16_t* op = out + (size_t)(frame * L + q) * D + h * 64 + 4 * G;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store_bf16x4(op + dt * 16, o[dt], inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int unite_teacher_qkv_attn(const void* h, const void* w_in, const float* b_in, void* out, int32_t BT, int32_t L, int32_t H,
+                                      int32_t D, float scale, void* stream) {
+    if (!h || !w_in || !b_in || !out || BT <= 0 || H <= 0 || D != H * 64) return UNITE_EINVAL;
+    if (L <= 192 || L > FQ_MROWS) return UNITE_ENOSUP;              // built for 14 key tiles (197 tokens: 14 x 14 patches + CLS)
+    const int64_t h_bytes = (int64_t)BT * L * D * 2, w_bytes = (int64_t)3 * D * D * 2;
+    if (h_bytes >= (int64_t)OOB_OFFSET || w_bytes >= (int64_t)OOB_OFFSET || (((uintptr_t)b_in) & 15)) return UNITE_ENOSUP;
+    static bool lds_ok = false;
+    if (!lds_ok) {
+        hipError_t e = hipFuncSetAttribute((const void*)teacher_qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS);
+        if (e != hipSuccess) return (int)e;
+        lds_ok = true;
+    }
+    hipLaunchKernelGGL(teacher_qkv_attn_kernel, dim3(BT * H), dim3(512), FQ_LDS, (hipStream_t)stream, (const uint16_t*)h, (const uint16_t*)w_in,
+                       b_in, (uint16_t*)out, L, H, D, scale, (uint32_t)h_bytes, (uint32_t)w_bytes);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

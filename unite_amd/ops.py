@@ -178,6 +178,16 @@ def im2col_gather(video, token_index, cols, P: int):
     return cols
 
 
+def teacher_qkv_attn(h, w_in, b_in, out, BT: int, L: int, H: int, scale: float):
+    """fused QKV projection + attention of the frozen teacher: h bf16 [BT*L, D] -> out bf16 [BT*L, D] (no qkv round trip)"""
+    lib = _lib.load()
+    _req(h, BF16, "h"); _req(w_in, BF16, "w_in"); _req(b_in, F32, "b_in"); _req(out, BF16, "out")
+    D = h.shape[1]
+    assert h.is_contiguous() and out.is_contiguous() and w_in.is_contiguous() and tuple(w_in.shape) == (3 * D, D) and h.shape[0] == BT * L
+    _lib.check(lib.unite_teacher_qkv_attn(_ptr(h), _ptr(w_in), _ptr(b_in), _ptr(out), BT, L, H, D, scale, _stream()), "unite_teacher_qkv_attn")
+    return out
+
+
 def clip_similarity(img, text, out, T: int, scale: float = 100.0):
     lib = _lib.load()
     _req(img, F32, "img"); _req(text, F32, "text"); _req(out, F32, "out")
