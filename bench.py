@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline : the CPU oracle (oracle/umt_oracle.py, fp32 torch) timed on this host's cores on a bounded sample.
 """
 import argparse
+import contextlib
 import ctypes as C
 import json
 import os
@@ -126,10 +127,11 @@ def main():
     model = DistributedDataParallel(student) if world > 1 else student
     total_batch = B * world
     args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1.5e-4 * total_batch / 256, opt_eps=1e-8, opt_betas=[0.9, 0.95])
-    opt = create_optimizer(args, student, skip_list=student.no_weight_decay())
-    scaler = NativeScalerWithGradNormCount()
     n_iter = a.warmup + 2 * a.steps + 4
-    lr_sched = cosine_scheduler(args.lr, 1e-5, 1, n_iter, warmup_epochs=0)
+    with contextlib.redirect_stdout(sys.stderr):                  # the reference's factories print their settings; stdout carries the JSON line only
+        opt = create_optimizer(args, student, skip_list=student.no_weight_decay())
+        lr_sched = cosine_scheduler(args.lr, 1e-5, 1, n_iter, warmup_epochs=0)
+    scaler = NativeScalerWithGradNormCount()
     reducer = getattr(model, "reducer", None)
     videos = torch.randn(B, 3, T, 224, 224, device=dev)           # synthetic, ImageNet-normalised-like; resident in HBM
     state = StepState()
