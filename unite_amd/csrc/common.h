@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16, LDS-DMA staging).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "unite_hip.h"
@@ -85,6 +86,23 @@ __device__ __forceinline__ u32x2 lds_read_tr16_raw(const char* p) {
 __device__ __forceinline__ bf16x8 tr_join(u32x2 lo, u32x2 hi) {
     const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8, v);
+}
+// 16-byte LDS read the compiler does not track either (same purpose: a register set filled for the NEXT group of MFMAs while the
+// current group runs; with the tracked read hipcc puts lgkmcnt(0) in front of the current group).  addr = LDS byte address,
+// OFF = immediate offset (< 64 KiB).  Fence with lds_tr_fence<true>() before the first use.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128_raw(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(LDS_AS const char*)p; }
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 template <bool ANY_TR>
 __device__ __forceinline__ void lds_tr_fence() {

@@ -14,13 +14,16 @@ namespace {
 
 constexpr int FQ_MROWS = 224, FQ_NT16 = 14;             // activation rows per frame (197 valid for a 14 x 14 grid + CLS), key tiles
 constexpr int FQ_A_BYTES = FQ_MROWS * 128, FQ_B_BYTES = 192 * 128, FQ_STAGE = FQ_A_BYTES + FQ_B_BYTES;      // 28 + 24 = 52 KiB
-constexpr int FQ_LDS = 3 * FQ_STAGE;                    // 156 KiB ring; the q / k / v images (84 KiB) reuse it afterwards
+constexpr int FQ_LDS = 3 * FQ_STAGE;
+#ifndef FQ_DEBUG
+#define FQ_DEBUG 0      // experiment builds only (-DFQ_DEBUG=n): 1 no attention, 2 no projection loop, 3 no MFMAs, 4 no MFMAs / fragment reads, 5 no DMA
+#endif                    // 156 KiB ring; the q / k / v images (84 KiB) reuse it afterwards
 
 __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t* __restrict__ hin, const uint16_t* __restrict__ w_in,
                                                                   const float* __restrict__ b_in, uint16_t* __restrict__ out, int L, int H,
                                                                   int D, float scale, uint32_t h_bytes, uint32_t w_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, G = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x & 63, G = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order (workgroups b, b + 8, ... share an XCD): each XCD gets a contiguous range of (frame, head) units, so the 12
     // heads of a frame read its activation rows from one L2 instead of eight
@@ -30,49 +33,132 @@ __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t
     const int wm = wave >> 2, wn = wave & 3;               // 8 waves: m-tiles wm*7 .. +7 (of 14), n-tiles wn*3 .. +3 (of 12)
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hin, 0, (int)h_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)w_in, 0, (int)w_bytes, 0x00020000);
-    const int nk = D / 64;
+    const int nk = FQ_DEBUG == 2 ? 0 : D / 64;
 
     // one K-tile: 224 activation rows (rows >= L read as zero; 28 pieces of 1 KiB: 7 per wave of waves 0-3) + the head's 3 x 64
-    // weight rows (24 pieces: 6 per wave of waves 4-7)
-    auto stage = [&](int t) {
+    // weight rows (24 pieces: 6 per wave of waves 4-7).  Lane (r8 = lane >> 3, p = lane & 7) of piece `it` moves 16 B of row
+    // it * 8 + r8; its swizzled chunk index depends on the lane only, so a piece's offset is a per-lane constant + it * 8 rows.
+    const int r8 = lane >> 3, p8 = lane & 7;
+    const int lc16 = ((((p8 >> 1) ^ ((r8 >> 1) & 3)) << 1) | (p8 & 1));
+    const int wq = wave & 3;
+    const uint32_t a_off0 = ((uint32_t)(frame * L + wq * 8 + r8) * D + lc16 * 8) * 2u;             // piece wq, K-tile 0
+    const uint32_t b_off0 = ((uint32_t)(h * 64 + wq * 8 + r8) * D + lc16 * 8) * 2u;                // q rows; k / v rows are + D * D elements
+    // i-th DMA of this wave for K-tile t: activation stagers i < 7, weight stagers i < 6
+    auto piece = [&](int t, int i, bool a_side) {
+        if (FQ_DEBUG == 5) return;
         char* buf = smem + (t % 3) * FQ_STAGE;
-        if (wave < 4) stage_rows(rsH, buf, FQ_MROWS, L, (uint32_t)(frame * L) * D + t * 64, D, wave, 4, lane);
-        else {
-#pragma unroll
-            for (int which = 0; which < 3; ++which)
-                stage_rows(rsW, buf + FQ_A_BYTES + which * 64 * 128, 64, 64, (uint32_t)(which * D + h * 64) * D + t * 64, D, wave - 4, 4, lane);
+        if (a_side) {
+            const int it = wq + 4 * i;
+            // L > 192: only the last piece (rows 192 + 8 wq ..) can run past the frame; those rows read as zero
+            const uint32_t voff = (i < 6 || it * 8 + r8 < L) ? a_off0 + (uint32_t)(i * 32 * D + t * 64) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (LDS_AS void*)(buf + it * 1024), 16, voff, 0, 0, 0);
+        } else {
+            const int which = i >> 1, it = wq + 4 * (i & 1);
+            const uint32_t voff = b_off0 + (uint32_t)(which * D * D + (i & 1) * 32 * D + t * 64) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (LDS_AS void*)(buf + FQ_A_BYTES + which * 8192 + it * 1024), 16, voff, 0, 0, 0);
         }
     };
-    stage(0);
-    if (nk > 1) stage(1);
-
+    auto stage = [&](int t) {
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) piece(t, i, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) piece(t, i, false);
+        }
+    };
+    // K-tile `t` has landed for this wave once only the DMAs of the `younger` tiles issued after it are outstanding
+    auto landed = [&](int younger) {
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) { if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if (wave < 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+    };
+    // fragment reads through untracked asm (common.h): lane-constant address per ks, m- / n-tile as immediate offset
+    const int c = lane & 15;
+    uint32_t la[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) la[ks] = lds_address(smem) + (uint32_t)row_addr(c, ks * 4 + G);
+    const uint32_t a_tiles = (uint32_t)(wm * 7 * 2048), b_tiles = (uint32_t)(FQ_A_BYTES + wn * 3 * 2048);
+    auto frags = [&](int t, int ks, bf16x8 (&xa)[7], bf16x8 (&wb)[3]) {
+        if (FQ_DEBUG == 4) return;
+        const uint32_t st = (uint32_t)((t % 3) * FQ_STAGE) + la[ks];
+        const uint32_t pa = st + a_tiles, pb = st + b_tiles;
+        static_for<0, 7>([&](auto i) { xa[decltype(i)::value] = lds_read_b128_raw<decltype(i)::value * 2048>(pa); });
+        static_for<0, 3>([&](auto j) { wb[decltype(j)::value] = lds_read_b128_raw<decltype(j)::value * 2048>(pb); });
+        __builtin_amdgcn_sched_barrier(0);                 // the MFMAs that follow stay behind the reads they are meant to cover
+    };
     f32x4 acc[7][3];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](const bf16x8 (&xa)[7], const bf16x8 (&wb)[3]) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (FQ_DEBUG == 3 || FQ_DEBUG == 4) asm volatile("" ::"v"(wb[j]), "v"(xa[i]));
+                else acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);      // C^T: rows = output columns
+            }
+    };
 
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K-tile t landed; t + 1 may still be in flight
-        else if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __syncthreads();                                                        // ... for every wave; all are done with K-tile t - 1
-        if (t + 2 < nk) stage(t + 2);
-        const char* At = smem + (t % 3) * FQ_STAGE;
-        const char* Bt = At + FQ_A_BYTES;
+    // the same with this wave's DMAs for K-tile t_new spread between the MFMA rows (one DMA per three MFMAs)
+    auto mm_dma = [&](const bf16x8 (&xa)[7], const bf16x8 (&wb)[3], int t_new, auto a_side_c) {
+        constexpr bool A_SIDE = decltype(a_side_c)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xa[7], wb[3];
+        for (int i = 0; i < 7; ++i) {
+            if (A_SIDE || i < 6) piece(t_new, i, A_SIDE);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) xa[i] = row_frag(At, (wm * 7 + i) * 16, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) wb[j] = row_frag(Bt, (wn * 3 + j) * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 7; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);      // C^T: rows = output columns
+            for (int j = 0; j < 3; ++j) {
+                if (FQ_DEBUG == 3 || FQ_DEBUG == 4) asm volatile("" ::"v"(wb[j]), "v"(xa[i]));
+                else acc[i][j] = mfma16(wb[j], xa[i], acc[i][j]);
+            }
         }
+    };
+
+    // Three K-tiles in the ring; the fragments of the next half K-tile are read from LDS while the MFMAs of the current one run
+    // (two register sets), one barrier per K-tile, after which the tile just finished (t) may be refilled with K-tile t + 3.
+    // Waves w and w + 4 share a SIMD: the activation stagers (0-3) spread their DMAs over the second-half MFMAs of iteration t,
+    // the weight stagers (4-7) over the first-half MFMAs of iteration t + 1, so one of the two is always issuing plain MFMAs.
+    // Either way K-tiles up to t + 2 have been issued when a wave waits for K-tile t + 1.
+    // Raw barriers: __syncthreads() would put "s_waitcnt vmcnt(0)" in front (the compiler makes the workgroup fence wait for the
+    // LDS-DMA it sees in flight), i.e. drain the whole prefetch queue every K-tile.
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    landed(min(nk - 1, 2));
+    __builtin_amdgcn_s_barrier();
+    bf16x8 xa0[7], wb0[3], xa1[7], wb1[3];
+    frags(0, 0, xa0, wb0);
+    lds_tr_fence<true>();
+    // one K-tile step; DMA_FIRST: weight stager, spreads K-tile t + 2 over the first half; DMA_SECOND: activation stager, K-tile t + 3
+    auto step = [&](int t, auto dma_first_c, auto dma_second_c) {
+        frags(t, 1, xa1, wb1);                             // in flight under the MFMAs of the first half
+        if constexpr (decltype(dma_first_c)::value) mm_dma(xa0, wb0, t + 2, std::false_type{});      // buffer of K-tile t - 1
+        else mm(xa0, wb0);
+        landed(min(nk - 2 - t, 1));                        // K-tile t + 1; only t + 2 was issued after it
+        lds_tr_fence<true>();                              // second-half fragments are in; this wave is done reading K-tile t
+        __builtin_amdgcn_s_barrier();
+        frags(t + 1, 0, xa0, wb0);                         // in flight under the MFMAs of the second half
+        if constexpr (decltype(dma_second_c)::value) mm_dma(xa1, wb1, t + 3, std::true_type{});      // buffer of K-tile t
+        else mm(xa1, wb1);
+        lds_tr_fence<true>();
+    };
+    // (every wave passes the same number of barriers: nk - 1 steps in either branch)
+    if (wave < 4) {
+        int t = 0;
+        for (; t + 3 < nk; ++t) step(t, std::false_type{}, std::true_type{});
+        for (; t + 1 < nk; ++t) step(t, std::false_type{}, std::false_type{});
+    } else {
+        int t = 0;
+        if (nk > 1) step(t++, std::false_type{}, std::false_type{});
+        for (; t + 2 < nk; ++t) step(t, std::true_type{}, std::false_type{});
+        for (; t + 1 < nk; ++t) step(t, std::false_type{}, std::false_type{});
     }
+    frags(nk - 1, 1, xa1, wb1);
+    mm(xa0, wb0);
+    lds_tr_fence<true>();
+    mm(xa1, wb1);
     __syncthreads();                                       // the ring is free: q | k | v images [224][64] bf16 go to its start
 
     // ---- bias, bf16, LDS images (attention.hip layout: 128-B rows, 32-B chunk c at c ^ ((row >> 1) & 3))
@@ -98,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t
     constexpr int NT16 = FQ_NT16;
     const float sl2 = scale * LOG2E;
     const int nqt = (L + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 8) {
+    for (int qt = wave; qt < (FQ_DEBUG == 1 ? 0 : nqt); qt += 8) {
         const int q = qt * 16 + c;
         const bf16x8 qf0 = row_frag(Qs, qt * 16, 0, lane), qf1 = row_frag(Qs, qt * 16, 1, lane);
         f32x4 st[NT16];
