@@ -317,7 +317,7 @@ def test_stage1_vitl_cfg5_vs_oracle():
 
 
 def test_streams_on_off_bit_identical_full_size():
-    """BASELINE config-2 shapes at B = 8: the step with every side stream on (two-stream teacher, overlapped target tail, weight
+    """BASELINE config-2 shapes at B = 8: the step with every side stream on (teacher frame ranges on three streams, overlapped target tail, weight
     gradients on their own stream) produces bit-identical gradients to the same step on one stream -- the arithmetic is the same
     and deterministic, so any difference would be a missing event / buffer-reuse race."""
     import unite_amd
@@ -335,6 +335,7 @@ def test_streams_on_off_bit_identical_full_size():
     vid = make_videos(B, 8, 224, 224, 5).to(DEV)
     imp = make_importance(B * 8, 196, 6).to(DEV)
     rt, trt = student.runtime(), teacher.runtime()
+    trt.min_frames_per_stream = 16                      # 64 frames here: three frame ranges on three streams, as at B = 32
     grads, attns = [], []
     for on in (False, True, True):                      # the concurrent form twice: steady-state buffer reuse included
         rt.runner.wgrad_stream, trt.two_streams = on, on
