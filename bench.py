@@ -195,18 +195,18 @@ def main():
         ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
         lib.unite_prof_summary(C.byref(ms), C.byref(cnt), C.byref(fl))
         lib.unite_prof_enable(0, 0)
-        print(f"[bench] profiled pass: {cnt.value} GEMM launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
+        print(f"[bench] profiled pass: {cnt.value} MFMA-kernel launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         traffic = None      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same command
         tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
         if os.path.exists(tp):
             traffic = round(json.load(open(tp))["traffic_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": "gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues)", "achieved": round(ach, 1),
+        roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM kernels: gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues) + teacher_qkv_attn_kernel (projection + attention FLOPs)", "achieved": round(ach, 1),
                 "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
-                "note": "HIP events on the launch stream around every GEMM launch in a second pass of the same steps, run on ONE stream "
+                "note": "HIP events on the launch stream around every launch of these kernels in a second pass of the same steps, run on ONE stream "
                         "(the timed region overlaps weight-gradient GEMMs and the two teacher halves on side streams, which would "
                         "charge each launch for time it shares with other kernels); same numbers as `bench.py --serial` under rocprofv3"}
     elif world > 1:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the GEMM launches of a bench run into
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the MFMA-kernel (GEMM family + teacher_qkv_attn) launches of a bench run into
 profiles/<name>.json:  python tools/pmc_traffic.py <fetch_csv> <write_csv> <out_json>
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2;
 WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB."""
@@ -7,7 +7,7 @@ import csv, json, sys
 def agg(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "gemm_" in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and ("gemm_" in r["Kernel_Name"] or "teacher_qkv_attn" in r["Kernel_Name"]) and "splitk_reduce" not in r["Kernel_Name"]:
             tot += float(r["Counter_Value"]); n += 1
     return tot, n
 f, nf = agg(sys.argv[1], "FETCH_SIZE")
@@ -15,6 +15,6 @@ w, nw = agg(sys.argv[2], "WRITE_SIZE")
 out = {"launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_per_launch_corrected": f * 1024 * 2 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1),
        "traffic_bytes_per_launch": f * 1024 * 2 / max(nf, 1) + w * 1024 / max(nw, 1),
-       "note": "GEMM launches of bench.py (all shapes of the stage-1 step); FETCH_SIZE x2 per the gfx950 correction"}
+       "note": "MFMA-kernel launches of bench.py (all GEMM shapes of the stage-1 step + the fused teacher projection/attention kernel); FETCH_SIZE x2 per the gfx950 correction"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)

@@ -955,6 +955,18 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     return UNITE_OK;
 }
 
+// the same timing pool for the other MFMA kernel of the step (teacher_fused.hip); not part of the C ABI
+bool unite_prof_begin(hipStream_t s) {
+    const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
+    if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
+    return prof;
+}
+void unite_prof_end(hipStream_t s, double flops) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+    g_prof.used++;
+    g_prof.flops += flops;
+}
+
 // ---- diagnostics (bench.py): HIP events around every GEMM launch, on the stream it is launched on
 extern "C" int unite_prof_enable(int32_t on, int32_t max_launches) {
     if (on) {
