@@ -352,6 +352,43 @@ def test_streams_on_off_bit_identical_full_size():
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
 
 
+def test_data_parallel_equivalence_full_size():
+    """The property data-parallel training rests on, at BASELINE config-2 model sizes without the oracle: the step on 8 clips equals
+    the mean of the steps on its two halves of 4 (loss) and the mean of their gradients (every clip is independent in teacher,
+    masks and student; the loss is a mean over clips).  Tolerance: fp32 reductions in a different order + the split-K / tile plan
+    of the GEMMs changing with M."""
+    import unite_amd
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    student = unite_amd.create_model("adaptation_umt_base_patch16_224", pretrained=False, drop_path_rate=0.0, num_frames=8,
+                                     tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+                                     clip_return_layers=[6, 7, 8, 9, 10, 11], use_cls_token=False, use_learnable_pos_emb=False,
+                                     use_checkpoint=False, checkpoint_num=0, clip_norm_type='l2', clip_student_return_interval=1,
+                                     drop_block_rate=None)
+    teacher = unite_amd.clip.clip_b16(pretrained=False, return_attn=True, clip_return_layers=[6, 7, 8, 9, 10, 11])
+    student.load_state_dict(fill_state_dict(student_shapes(O.StudentCfg()), 13))
+    teacher.load_state_dict(fill_state_dict(teacher_shapes(O.TeacherCfg()), 14))
+    student, teacher = student.to(DEV).train(), teacher.to(DEV)
+    B = 8
+    vid = make_videos(B, 8, 224, 224, 15).to(DEV)
+    imp = make_importance(B * 8, 196, 16).to(DEV)
+    rt = student.runtime()
+
+    def run(lo, hi):
+        rt.fp.accumulate = False
+        loss = stage1_step(student, teacher, vid[lo:hi].contiguous(), hi - lo, 0.8, 'attention', None, 'mixed', StepState(),
+                           importance=imp[lo * 8:hi * 8].contiguous())
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), rt.fp.grad.clone()
+
+    l_all, g_all = run(0, B)
+    l_a, g_a = run(0, B // 2)
+    l_b, g_b = run(B // 2, B)
+    assert abs(l_all - 0.5 * (l_a + l_b)) <= 2e-5 * abs(l_all)
+    g_mean = 0.5 * (g_a + g_b)
+    assert rel_l2(g_all, g_mean) <= 2e-3
+
+
 def test_train_one_epoch_synthetic():
     """The drop-in engine on a synthetic loader: attention-guided masks, 6 steps, loss goes down, meters come back."""
     import unite_amd

@@ -116,3 +116,34 @@ def test_vit_stage2_drop_path_vs_oracle():
         x = O.vit_block(x, sd, f"blocks.{i}.", 2, 1e-6, rates[i], True, (u[i, 0], u[i, 1]))
     ref = torch.nn.functional.linear(O.layer_norm(x.mean(1), sd["fc_norm.weight"], sd["fc_norm.bias"], 1e-6), sd["head.weight"], sd["head.bias"])
     torch.testing.assert_close(logits.detach().cpu(), ref, atol=2e-2, rtol=2e-2)
+
+
+def test_stage2_full_size_batch_split_equivalence():
+    """BASELINE config 3 at its full sequence length (ViT-B/16, 16 f x 224^2 = 3136 tokens: the flash-style tiled attention kernels,
+    forward and both backward kernels) through a size-independent property: CE over 2 clips = mean of the two single-clip losses, and
+    the gradients are the mean of the single-clip gradients.  No oracle at this size (a CPU pass takes minutes)."""
+    import unite_amd
+    m = unite_amd.create_model("vit_base_patch16_224", pretrained=False, num_classes=8, all_frames=16, tubelet_size=1,
+                               use_mean_pooling=True, drop_path_rate=0.0, init_scale=0.001).to(DEV).train()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        m.head.weight.copy_(torch.randn(8, 768, generator=g) * 0.05)          # init_scale 0.001 would make the logits ~0
+    vid = make_videos(2, 16, 224, 224, seed=12).to(DEV)
+    labels = torch.tensor([3, 6], device=DEV)
+    rt = m.runtime()
+
+    def run(lo, hi):
+        rt.fp.accumulate = False
+        logits = m(vid[lo:hi].contiguous())
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels[lo:hi])
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(logits).all()
+        return loss.item(), rt.fp.grad.clone()
+
+    l_all, g_all = run(0, 2)
+    l_a, g_a = run(0, 1)
+    l_b, g_b = run(1, 2)
+    assert abs(l_all - 0.5 * (l_a + l_b)) <= 1e-4 * max(1.0, abs(l_all))
+    assert g_all.abs().max() > 0
+    assert rel_l2(g_all, 0.5 * (g_a + g_b)) <= 2e-3
