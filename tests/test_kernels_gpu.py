@@ -322,7 +322,7 @@ def test_attention_softmax_spike(ops):
     torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1)])
+@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1), (256, 197, 12)])
 def test_teacher_fused_qkv_attention_matches_unfused(ops, BT, L, H):
     """unite_teacher_qkv_attn (projection + attention in one workgroup per frame and head, qkv never written) against the two
     kernels it replaces on the same inputs: same f32 accumulation order, same bf16 roundings -> identical bits expected; the
