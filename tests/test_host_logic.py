@@ -102,3 +102,62 @@ def test_metric_logger_and_scaler_surface():
     assert m.meters["loss"].global_avg == 1.5 and "weight_decay" not in m.meters
     assert NativeScalerWithGradNormCount().state_dict() == {"scale": 1.0}
     assert list(m.log_every(range(3), 0)) == [0, 1, 2]
+
+
+def test_distributed_sampler_matches_reference_golden(golden_dir):
+    """unite_amd.data.DistributedSampler (shuffle / seed + epoch / drop_last / repetitions / wrap-around padding) against the index
+    streams of the reference's sampler for every rank (tests/golden/sampler.json, written by oracle/make_golden_sampler.py from
+    src/datasets/distributed.py:81-163); plus the properties data-parallel training relies on."""
+    import json
+    from unite_amd.data import DistributedSampler
+    cases = json.load(open(os.path.join(golden_dir, "sampler.json")))["cases"]
+    assert len(cases) >= 10
+    for c in cases:
+        ds = list(range(c["n"]))
+        seen = []
+        for r in range(c["num_replicas"]):
+            s = DistributedSampler(ds, num_replicas=c["num_replicas"], rank=r, shuffle=c["shuffle"], seed=c["seed"],
+                                   drop_last=c["drop_last"], repetitions=c["repetitions"])
+            s.set_epoch(c["epoch"])
+            idx = list(iter(s))
+            assert idx == c["indices"][r], (c["n"], c["num_replicas"], r)
+            assert len(s) == len(idx)
+            assert list(iter(s)) == idx                       # same epoch -> same stream
+            seen += idx
+        # every rank draws the same number of samples; together they cover the epoch (each sample `repetitions` times when the
+        # world size divides the epoch, at least floor(.) times with drop_last, at least that often with padding)
+        total = c["n"] * c["repetitions"]
+        counts = np.bincount(np.array(seen), minlength=c["n"])
+        if total % c["num_replicas"] == 0:
+            assert (counts == c["repetitions"]).all()
+        elif c["drop_last"]:
+            assert counts.sum() == total - total % c["num_replicas"] and counts.max() <= c["repetitions"]
+        else:
+            assert (counts >= c["repetitions"]).all()
+    with pytest.raises(ValueError):
+        DistributedSampler([0, 1], num_replicas=2, rank=2)
+
+
+def test_sparse_frame_sampling_properties():
+    """unite_amd.data.sample_train_indices / frame_id_list (reference src/datasets/mae.py:253-287; parity unpinned -- the reference
+    module cannot be imported without decord / cv2): one frame per segment, inside its segment, inside the video, reproducible from
+    the generator state, degenerate videos handled as the reference does (zeros)."""
+    from unite_amd.data import frame_id_list, sample_train_indices
+    rs = np.random.RandomState(0)
+    for num_frames, segs in [(300, 8), (64, 16), (17, 16), (16, 16), (9, 8)]:
+        off, skip = sample_train_indices(num_frames, segs, rng=rs)
+        assert len(off) == segs and len(skip) == 1 and (skip == 0).all()
+        seg_len = num_frames // segs
+        ids = frame_id_list(num_frames, off, skip)
+        assert len(ids) == segs and all(0 <= i < num_frames for i in ids)
+        if seg_len > 0:
+            for k, i in enumerate(ids):
+                assert k * seg_len <= i < (k + 1) * seg_len
+        assert ids == sorted(ids)
+    off, _ = sample_train_indices(5, 8, rng=rs)                  # shorter than the segment count: every frame id is 0
+    assert frame_id_list(5, off, [0]) == [0] * 8
+    a = sample_train_indices(300, 8, skip_length=4, new_step=2, temporal_jitter=True, rng=np.random.RandomState(3))
+    b = sample_train_indices(300, 8, skip_length=4, new_step=2, temporal_jitter=True, rng=np.random.RandomState(3))
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and len(a[1]) == 2 and set(a[1]) <= {0, 1}
+    ids = frame_id_list(300, a[0], a[1], skip_length=4, new_step=2)
+    assert len(ids) == 16 and all(0 <= i < 300 for i in ids)
