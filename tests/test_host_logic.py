@@ -161,3 +161,24 @@ def test_sparse_frame_sampling_properties():
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and len(a[1]) == 2 and set(a[1]) <= {0, 1}
     ids = frame_id_list(300, a[0], a[1], skip_length=4, new_step=2)
     assert len(ids) == 16 and all(0 <= i < 300 for i in ids)
+
+
+def test_driver_side_utils_surface():
+    """every ``utils.*`` name the reference drivers touch (run_stage1/2/3.py) exists in unite_amd.utils with the reference's behaviour
+    for the pure-host ones (utils.py:84-87, 854-909)"""
+    from unite_amd import utils
+    for name in ["is_main_process", "get_world_size", "get_rank", "cosine_scheduler", "seed_worker", "load_state_dict", "count_parameters",
+                 "auto_load_model", "save_latest_model", "SmoothedValue", "MetricLogger", "save_model", "init_distributed_mode",
+                 "TensorboardLogger", "step_scheduler", "save_on_master", "experiment_exists", "confirm_exp_overwrite", "clip_infer",
+                 "setup_clip", "get_greedy_masks", "create_ds_config", "multiple_samples_collate", "multiple_pretrain_samples_collate",
+                 "str2bool", "get_class_names", "NativeScalerWithGradNormCount", "get_grad_norm_"]:
+        assert hasattr(utils, name), name
+    assert utils.str2bool("True") and utils.str2bool(True) and not utils.str2bool("no")
+    assert [len(utils.get_class_names(SimpleNamespace(nb_classes=n))) for n in (8, 12, 23)] == [8, 12, 23]
+    batch = [([torch.zeros(2), torch.ones(2)], [1, 2], [7, 7], {"a": 1}), ([torch.zeros(2), torch.ones(2)], [3, 4], [8, 8], {"a": 2})]
+    x, y, idx, extra = utils.multiple_samples_collate(batch)
+    assert x.shape == (4, 2) and y.tolist() == [1, 2, 3, 4] and idx.tolist() == [7, 7, 8, 8] and extra["a"].tolist() == [1, 2]
+    assert isinstance(utils.multiple_samples_collate(batch, fold=True)[0], list)
+    assert utils.count_parameters(torch.nn.Linear(3, 4)) == 16
+    with pytest.raises(NotImplementedError):
+        utils.setup_clip(None, None)

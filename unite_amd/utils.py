@@ -355,3 +355,118 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
             if 'scaler' in ckpt:
                 loss_scaler.load_state_dict(ckpt['scaler'])
         print("Resume checkpoint %s" % args.resume)
+
+
+# ----------------------------------------------------------------------------- small driver-side helpers (utils.py:70-88,426-480,854-925)
+# Not on the hot path; present so that ``from unite_amd import utils`` covers every ``utils.*`` name the reference drivers touch.
+def str2bool(v):
+    return v if isinstance(v, bool) else v.lower() in ("yes", "true", "t", "1")
+
+
+_CLASS_NAMES = {       # label sets of the three benchmarks (utils.py:70-82): class prompts of the zero-shot CLIP classifier
+    8: ['drink', 'jump', 'pick', 'pour', 'push', 'run', 'walk', 'wave'],
+    12: ['climb', 'fencing', 'golf', 'soccer', 'pullup', 'boxing', 'pushup', 'riding bike', 'horse riding', 'basketball', 'archery',
+         'walking'],
+    23: ['archery', 'baseball', 'basketball', 'biking', 'bowling', 'swimming', 'diving', 'fencing', 'field hockey', 'gymnastics', 'golf',
+         'horse riding', 'kayaking', 'rock climbing', 'climbing rope', 'skateboarding', 'skiing', 'sumo wrestling', 'surfing', 'tai chi',
+         'tennis', 'trampoline jumping', 'volleyball'],
+}
+
+
+def get_class_names(args):
+    if args.nb_classes not in _CLASS_NAMES:
+        raise NotImplementedError
+    return list(_CLASS_NAMES[args.nb_classes])
+
+
+def setup_clip(args, device):
+    raise NotImplementedError("utils.setup_clip loads OpenAI CLIP ('clip.load') and tokenises class prompts: the text tower and its "
+                              "weights are outside the built path.  Build the image side with unite_amd.clip.clip_b16(return_cls=...) "
+                              "weights and pass text features to utils.clip_infer(model, videos, text_features).")
+
+
+def create_ds_config(args):
+    raise NotImplementedError("DeepSpeed is out of scope (enable_deepspeed: false in every UNITE config)")
+
+
+class TensorboardLogger(object):
+    """scalar logger with the reference's interface (set_step / update(head, step, **scalars) / flush); needs tensorboardX or
+    torch.utils.tensorboard at construction time"""
+
+    def __init__(self, log_dir):
+        try:
+            from tensorboardX import SummaryWriter
+            self.writer = SummaryWriter(logdir=log_dir)
+        except ImportError:
+            from torch.utils.tensorboard import SummaryWriter        # raises ImportError if tensorboard is absent as well
+            self.writer = SummaryWriter(log_dir=log_dir)
+        self.step = 0
+
+    def set_step(self, step=None):
+        self.step = step if step is not None else self.step + 1
+
+    def update(self, head='scalar', step=None, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            assert isinstance(v, (float, int))
+            self.writer.add_scalar(head + "/" + k, v, self.step if step is None else step)
+
+    def flush(self):
+        self.writer.flush()
+
+
+def seed_worker(worker_id):
+    """DataLoader worker_init_fn: numpy / random seeded from the worker's torch seed"""
+    import random
+    s = torch.initial_seed() % 2 ** 32
+    np.random.seed(s)
+    random.seed(s)
+
+
+def setup_for_distributed(is_master):
+    """print() only on the master process (``force=True`` overrides)"""
+    import builtins
+    plain = builtins.print
+
+    def _print(*args, **kwargs):
+        if kwargs.pop('force', False) or is_master:
+            plain(*args, **kwargs)
+
+    builtins.print = _print
+
+
+def _flatten_collate(columns, flat):
+    from torch.utils.data.dataloader import default_collate
+    return [default_collate([x for sub in col for x in sub] if i in flat else list(col)) for i, col in enumerate(columns)]
+
+
+def multiple_samples_collate(batch, fold=False):
+    """repeated augmentation: every dataset item carries several samples; flatten inputs / labels / indices, keep extra_data per item"""
+    inputs, labels, video_idx, extra = _flatten_collate(list(zip(*batch)), flat={0, 1, 2})
+    return ([inputs] if fold else inputs), labels, video_idx, extra
+
+
+def multiple_pretrain_samples_collate(batch, fold=False):
+    data, mask = _flatten_collate(list(zip(*batch)), flat={0, 1})
+    return ([data] if fold else data), mask
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def experiment_exists(dir):
+    """a directory (whose path does not contain 'scrap') that already holds a .pth checkpoint"""
+    return os.path.isdir(dir) and 'scrap' not in dir and any(f.endswith(".pth") for f in os.listdir(dir))
+
+
+def confirm_exp_overwrite(output_dir):
+    answer = input("Experiment already exists in {}. Overwrite? (y/n): ".format(output_dir)).lower()
+    if answer == "y":
+        return output_dir
+    if answer == "n":
+        return str(Path(output_dir).parent / input("Enter new directory name: "))
+    raise ValueError("Invalid input. Enter 'y' or 'n'.")
