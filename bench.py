@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one HIP stream for the whole run (no side-stream weight gradients, no two-stream "
+    ap.add_argument("--serial", action="store_true", help="one HIP stream for the whole run (no side-stream weight gradients, no multi-stream "
                                                           "teacher): per-kernel durations are then undisturbed, as in the roofline pass")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of the N>1 flow on one GPU)")
     a = ap.parse_args()
@@ -176,7 +176,7 @@ def main():
     clips_s = total_batch * a.steps / dt
 
     def set_concurrency(on: bool):
-        """side-stream weight gradients (student) and the two-stream teacher; off = every kernel alone on the GPU"""
+        """side-stream weight gradients (student) and the teacher's frame ranges on their own streams; off = every kernel alone on the GPU"""
         student.runtime().runner.wgrad_stream = on
         teacher.runtime().two_streams = on
         state.overlap_targets = on
@@ -207,7 +207,7 @@ def main():
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
                 "note": "HIP events on the launch stream around every launch of these kernels in a second pass of the same steps, run on ONE stream "
-                        "(the timed region overlaps weight-gradient GEMMs and the two teacher halves on side streams, which would "
+                        "(the timed region overlaps weight-gradient GEMMs and the teacher's frame ranges on side streams, which would "
                         "charge each launch for time it shares with other kernels); same numbers as `bench.py --serial` under rocprofv3"}
     elif world > 1:
         # keep ranks in lock-step with rank 0's profiled pass
