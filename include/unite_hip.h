@@ -50,7 +50,7 @@ const char* unite_target_arch(void);
  *   v *= row_scale[m / rows_per_scale]             (row_scale != NULL; stochastic depth)
  *   v += residual[m,n]                             (residual != NULL, f32, ld = ldr)
  *   v += out[m,n]                                  (accumulate != 0, f32 out only)
- *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given.
+ *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given;  colsum_out (+)= column sums of out.
  * ------------------------------------------------------------------------------------ */
 enum { UNITE_ACT_NONE = 0, UNITE_ACT_GELU = 1, UNITE_ACT_QUICKGELU = 2, UNITE_ACT_DGELU = 3 };
 
@@ -70,7 +70,15 @@ typedef struct unite_gemm_args {
     void* workspace; int64_t workspace_bytes;   /* optional scratch (16-byte aligned): lets short-and-wide products with a plain
                                                    f32 output (weight gradients) run split-K through f32 slabs [S][M][N],
                                                    summed in a fixed order (bitwise reproducible); NULL = never split */
+    float* colsum_out; int32_t colsum_accumulate;
+                                                /* optional f32 [N]: colsum_out[n] (+)= sum over m of the STORED out[m,n] (after rounding
+                                                   for a bf16 output) -- the bias gradient of the Linear whose input gradient this
+                                                   product is (db = colsum(dY), modeling_finetune.py:67 under autograd), so that dY is
+                                                   not read again for it.  Per-tile partial sums go through `workspace`
+                                                   (>= unite_gemm_colsum_workspace(M, N) bytes), summed in a fixed order. */
 } unite_gemm_args;
+
+size_t unite_gemm_colsum_workspace(int32_t M, int32_t N);
 
 int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
 

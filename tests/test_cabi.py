@@ -33,7 +33,7 @@ def test_ctypes_table_matches_header():
     assert lib.unite_abi_version() == 1
     assert lib.unite_target_arch() == b"gfx950"
     # struct layout: the header's unite_gemm_args has 10 pointer-or-int64 and 17 int32 fields
-    assert ctypes.sizeof(_lib.GemmArgs) % 8 == 0 and len(_lib.GemmArgs._fields_) == 27
+    assert ctypes.sizeof(_lib.GemmArgs) % 8 == 0 and len(_lib.GemmArgs._fields_) == 29
 
 
 def test_workspace_queries_run_without_gpu():

@@ -156,6 +156,29 @@ def test_gemm_epilogues(ops):
     assert float(big[:, :N].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,f32", [(300, 200, 192, False), (1000, 520, 128, False), (640, 256, 320, True), (10240, 3072, 768, False)])
+def test_gemm_fused_column_sums(ops, M, N, K, f32):
+    """colsum_out of unite_gemm_bf16 (bias gradient out of the input-gradient GEMM's epilogue) = column sums of the STORED output,
+    i.e. what a separate pass over the bf16 output would add up; overwrite and accumulate forms; ragged tiles."""
+    a = bf(rnd(M, K, seed=1)).to(DEV)
+    b = bf(rnd(N, K, seed=2, scale=K ** -0.5)).to(DEV)
+    out = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    ref_out = torch.empty_like(out)
+    ops.gemm(a, b, ref_out)
+    ws = torch.empty(ops.gemm_colsum_workspace(M, N), dtype=torch.uint8, device=DEV)
+    cs = torch.full((N,), float("nan"), device=DEV)
+    ops.gemm(a, b, out, workspace=ws, colsum_out=cs)
+    assert torch.equal(out, ref_out)                                   # the product itself is unchanged
+    ref = ref_out.double().sum(0)
+    torch.testing.assert_close(cs.double(), ref, atol=2e-3 * (M ** 0.5), rtol=1e-4)      # f32 sums of M values in another order
+    cs2 = cs.clone()
+    ops.gemm(a, b, out, workspace=ws, colsum_out=cs2, colsum_accumulate=True)
+    torch.testing.assert_close(cs2, 2 * cs, atol=0, rtol=1e-6)
+    cs3 = torch.empty(N, device=DEV)
+    ops.gemm(a, b, out, workspace=ws, colsum_out=cs3)
+    assert torch.equal(cs3, cs)                                         # deterministic
+
+
 def test_gemm_rejects_bad_arguments(ops):
     from unite_amd._lib import UniteHipError
     a = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)      # K = 12: rows are not 16-byte multiples

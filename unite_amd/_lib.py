@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("out", c_p), ("ldc", c_i), ("out_f32", c_i), ("accumulate", c_i),
         ("out_bf16_copy", c_p), ("ld_copy", c_i),
         ("workspace", c_p), ("workspace_bytes", c_i64),
+        ("colsum_out", c_p), ("colsum_accumulate", c_i),
     ]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "unite_abi_version": (c_i, []),
     "unite_target_arch": (C.c_char_p, []),
     "unite_gemm_bf16": (c_i, [C.POINTER(GemmArgs), c_p]),
+    "unite_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "unite_gemm_bf16_grouped": (c_i, [C.POINTER(GemmArgs), c_i, c_p]),
     "unite_prof_enable": (c_i, [c_i, c_i]),
     "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),

@@ -42,6 +42,7 @@ struct Params {
     int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
     float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
     int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
+    float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
 };
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 // The bias chunk (b0|b1) is loaded by the caller ONCE per tile, ahead of the stores: vmcnt retires in issue order, so a
 // load issued between the stores of two passes could only be waited for together with every store before it.
 __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm_args& g, int slice, int gm, int gn, f32x4 v0, f32x4 v1,
-                                               f32x4 b0, f32x4 b1) {
+                                               f32x4 b0, f32x4 b1, float* csum = nullptr) {
     if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
         float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
         *(f32x4*)sp = v0;
@@ -166,6 +167,19 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
     if (g.out_bf16_copy) {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
+    }
+    if (csum) {      // column sums of what was stored (a later colsum over a bf16 output would read the rounded values)
+        if (g.out_f32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t w = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                csum[2 * e] += __uint_as_float(w << 16);
+                csum[2 * e + 1] += __uint_as_float(w & 0xFFFF0000u);
+            }
+        }
     }
 }
 
@@ -506,6 +520,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const int G = lane >> 4, c16 = lane & 15;
     constexpr int CPR = TILE / 8;                     // 8-column chunks per row
     const int ccol = (tid % CPR) * 8;                 // this thread's column chunk is the same in every pass
+    float csum_v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* const csum = p.colsum_partial ? csum_v : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -523,9 +539,23 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             const int lr = (tid + e * 4 * HALF) / CPR;
             const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
             const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
-            if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1);
+            if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1, csum);
         }
         __syncthreads();
+    }
+    if (csum) {
+        // this thread's sums cover its rows of column chunk ccol; the 4 * HALF / CPR threads of a column chunk meet in LDS and
+        // leave ONE partial row per tile: colsum_partial[tile row][n] (summed over tile rows by colsum_rows_kernel, fixed order)
+        constexpr int NG = 4 * HALF / CPR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[(tid / CPR) * TILE + ccol + e] = csum_v[e];
+        __syncthreads();
+        if (tid < TILE && n0 + tid < g.N) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < NG; ++r) a += cs[r * TILE + tid];
+            p.colsum_partial[(size_t)(m0 / TILE) * g.N + n0 + tid] = a;
+        }
     }
 }
 
@@ -755,6 +785,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// colsum_out[n] (+)= sum over tile rows of the per-tile column sums the deep kernels' epilogue left (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
+                                                          int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < N)
+        for (int i = r; i < nparts; i += 4) a += partial[(size_t)i * N + c];
+    red[r][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (r == 0 && c < N) {
+        const int l = threadIdx.x;
+        a = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        out[c] = accumulate ? out[c] + a : a;
+    }
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Joint choice of kernel and split-K factor from a cost model fitted on MI355X (us):
@@ -762,7 +809,7 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // kind 1: 128^2 tile, 512 resident (2 / CU), (c, e) = (1.006, 4.4);  kind 2: 256^2, 256 resident, (1.51, 9.8);
 // kind 3: 128 x 256, 512 resident, (1.58, 9.0).  S > 1 only for plain f32 outputs with a workspace (weight gradients).
 struct Plan { int kind, splitk; double cost; };
-inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind) {
+inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only = false) {
     const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
     const int slots[4] = {0, 512, 256, 512};
     const double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
@@ -770,6 +817,7 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
     Plan best = {1, 1, 1e30};
     for (int kind = 1; kind <= 3; ++kind) {
         if (only_kind && kind != only_kind) continue;
+        if (deep_only && kind == 3) continue;
         for (int S = 1; S <= 16; ++S) {
             if (S > 1 && (!can_split || (size_t)S * M * N * sizeof(float) > ws_bytes || kt / S < 4)) break;
             const int kts = (kt + S - 1) / S;
@@ -843,6 +891,7 @@ extern "C" int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t coun
     static const int dbg = getenv("UNITE_GEMM_DEBUG_SKIP") ? atoi(getenv("UNITE_GEMM_DEBUG_SKIP")) : 0;
     p.debug_skip = dbg;
     p.nt_store = 0;
+    p.colsum_partial = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
@@ -879,8 +928,15 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     const int only = !force ? 0 : !strcmp(force, "deep256") ? 2 : !strcmp(force, "wide") ? 3 : 1;
     const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
     const bool can_split = plain && g.workspace && aligned16(g.workspace);
-    const Plan plan = plan_gemm(g.M, g.N, g.K, can_split, (size_t)g.workspace_bytes, only);
-    const int kind = (force && !strcmp(force, "simple")) ? 0 : plan.kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2, 3 wide
+    // column sums of the output come out of the deep kernels' epilogue (per-tile-row partials in the workspace, then one small
+    // reduction): no split-K, no wide / simple kernel for such a product
+    const bool want_colsum = g.colsum_out != nullptr;
+    if (want_colsum && (!g.workspace || !aligned16(g.workspace) ||
+                        (size_t)g.workspace_bytes < unite_gemm_colsum_workspace(g.M, g.N) || (((uintptr_t)g.colsum_out) & 3))) return UNITE_EINVAL;
+    const Plan plan = plan_gemm(g.M, g.N, g.K, can_split && !want_colsum, (size_t)g.workspace_bytes, want_colsum && only != 2 ? (only == 3 ? 0 : only) : only,
+                                want_colsum);
+    const int kind = (force && !strcmp(force, "simple") && !want_colsum) ? 0 : plan.kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2, 3 wide
+    p.colsum_partial = want_colsum ? (float*)g.workspace : nullptr;
     const int tiles = kind == 2 ? ((g.M + 255) / 256) * ((g.N + 255) / 256)
                     : kind == 3 ? ((g.M + 127) / 128) * ((g.N + 255) / 256) : ((g.M + 127) / 128) * ((g.N + 127) / 128);
     p.splitk = 1;
@@ -946,6 +1002,11 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)p.slab, p.splitk, g.M, g.N, (float*)g.out, g.ldc,
                            g.accumulate);
     }
+    if (want_colsum) {
+        const int tile_m = kind == 2 ? 256 : 128;
+        hipLaunchKernelGGL(colsum_rows_kernel, dim3((g.N + 63) / 64), dim3(256), 0, s, (const float*)p.colsum_partial, (g.M + tile_m - 1) / tile_m,
+                           g.N, g.colsum_out, g.colsum_accumulate);
+    }
     if (prof) {
         (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
         g_prof.used++;
@@ -954,6 +1015,8 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
+
+extern "C" size_t unite_gemm_colsum_workspace(int32_t M, int32_t N) { return (size_t)((M + 127) / 128) * (size_t)N * sizeof(float); }
 
 // the same timing pool for the other MFMA kernel of the step (teacher_fused.hip); not part of the C ABI
 bool unite_prof_begin(hipStream_t s) {

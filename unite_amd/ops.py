@@ -49,13 +49,24 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
          aux_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 1,
          residual: Optional[torch.Tensor] = None, accumulate: bool = False,
-         out_bf16_copy: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views."""
+         out_bf16_copy: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+         colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> torch.Tensor:
+    """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views.
+    colsum_out (f32 [N]) (+)= column sums of the stored out (needs workspace >= gemm_colsum_workspace(M, N) bytes)."""
     lib = _lib.load()
     g = _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scale, rows_per_scale, residual, accumulate,
                    out_bf16_copy, workspace)
+    if colsum_out is not None:
+        _req(colsum_out, F32, "colsum_out")
+        if colsum_out.numel() != out.shape[1]:
+            raise ValueError("colsum_out must have N elements")
+        g.colsum_out, g.colsum_accumulate = _ptr(colsum_out), int(colsum_accumulate)
     _lib.check(lib.unite_gemm_bf16(C.byref(g), _stream()), "unite_gemm_bf16")
     return out
+
+
+def gemm_colsum_workspace(M: int, N: int) -> int:
+    return int(_lib.load().unite_gemm_colsum_workspace(M, N))
 
 
 def gemm_grouped(problems):

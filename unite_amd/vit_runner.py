@@ -71,6 +71,7 @@ class ViTRunner:
         self._slot = ""
         self.scale = 64 ** -0.5                 # head_dim ** -0.5 (modeling_finetune.py:86)
         self.wgrad_stream = os.environ.get("UNITE_WGRAD_STREAM", "1") != "0"
+        self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
 
     def _side_stream(self):
@@ -205,6 +206,7 @@ class ViTRunner:
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
         gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
+        gcws = ws.bytes_("gemm.cs.ws", ops.gemm_colsum_workspace(M, Hd))
         # Weight-gradient GEMMs and bias column sums are off the critical path (nothing in the backward chain reads them): they
         # run on a side HIP stream behind events, concurrently with the next dgrad GEMM / LayerNorm backward / attention backward
         # on the main stream, which leave MFMA or HBM headroom.  Their operands (dz, dx1b, dqkv, the incoming dxb) live in
@@ -238,14 +240,20 @@ class ViTRunner:
                 retire(i + 2)                       # its side work read the parity buffers this block is about to overwrite
             # ---- MLP branch
             dz = ws.get(f"bw.dz{par}", (M, Hd), BF16)
-            ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
+            # the fc1 bias gradient = column sums of dz comes out of this GEMM's epilogue (dz is not read again for it)
+            if self.fused_colsum:
+                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"], workspace=gcws,
+                         colsum_out=w["g:mlp.fc1.bias"], colsum_accumulate=acc)
+            else:
+                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
             # (one grouped launch of the block's four weight gradients -- ops.gemm_grouped -- is 12 % faster in isolation at 10 240
             # tokens but slower in the step: its 252 MB of operands have left the Infinity Cache by the end of the block)
 
             def mlp_wgrads(dxb=dxb, dz=dz, w=w, s=s):
                 ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
                 ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-                ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
+                if not self.fused_colsum:
+                    ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
             on_side(mlp_wgrads)
             dh2 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
