@@ -69,6 +69,24 @@ def main():
             dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device=DEV)
             t = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, delta, dqkv, B, N, H, 0.125))
             print(f"attn bwd {nm:8s} B={B} N={N}  {t*1e6:9.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (5 products)", flush=True)
+    print("== teacher projection + attention in one kernel (unite_teacher_qkv_attn) vs the GEMM + attention pair")
+    BT, L, H = 256, 197, 12
+    D = H * 64
+    hx = torch.randn(BT * L, D, device=DEV).to(torch.bfloat16)
+    w_in = (torch.randn(3 * D, D, device=DEV) * D ** -0.5).to(torch.bfloat16)
+    b_in = torch.randn(3 * D, device=DEV) * 0.1
+    qkv = torch.empty(BT * L, 3 * D, dtype=torch.bfloat16, device=DEV)
+    o = torch.empty(BT * L, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(BT, H, L, device=DEV)
+    fl = 2.0 * BT * L * 3 * D * D + 4.0 * BT * H * L * L * 64
+
+    def pair():
+        ops.gemm(hx, w_in, qkv, bias=b_in)
+        ops.attn_fwd(qkv, o, lse, BT, L, H, 0.125)
+    t = timeit(pair)
+    print(f"qkv GEMM + attention        {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+    t = timeit(lambda: ops.teacher_qkv_attn(hx, w_in, b_in, o, BT, L, H, 0.125))
+    print(f"fused kernel                {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
     print("== streaming kernels")
     M, D = Ms, 768
     x = torch.randn(M, D, device=DEV); g = torch.ones(D, device=DEV); b = torch.zeros(D, device=DEV)
