@@ -41,6 +41,7 @@ def test_workspace_queries_run_without_gpu():
     assert ops.layernorm_bwd_workspace(10240, 768) == (10240 // 16) * 3 * 768 * 4
     assert ops.colsum_workspace(1000, 776) > 0
     assert ops.grad_norm_workspace(88_005_888) > 0
+    assert ops.gemm_colsum_workspace(10240, 3072) == 80 * 3072 * 4          # one partial row per 128 output rows
 
 
 def test_no_cpu_fallback():
