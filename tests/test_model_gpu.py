@@ -389,6 +389,37 @@ def test_data_parallel_equivalence_full_size():
     assert rel_l2(g_all, g_mean) <= 2e-3
 
 
+@pytest.mark.parametrize("which", ["source", "target"])
+def test_stage1_loss_data_slices_vs_oracle(which):
+    """clip_loss_data = 'source' / 'target' (run_stage1.py:418-427: the distillation loss over the first n_source clips of the mixed
+    batch, or over the rest) with an explicit tube mask handed in as the dataset would (bool_masked_pos, mask_type != 'attention'):
+    loss and every gradient against the oracle evaluated on that slice of the batch."""
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    s, t = build_tiny()
+    ssd, tsd = fill_state_dict(student_shapes(TINY_S), 41), fill_state_dict(teacher_shapes(TINY_T), 42)
+    s.load_state_dict(ssd)
+    t.load_state_dict(tsd)
+    s, t = s.to(DEV).train(), t.to(DEV)
+    B, T, N = 3, TINY_S.num_frames, (TINY_S.img_size // TINY_S.patch_size) ** 2
+    vid = make_videos(B, T, TINY_S.img_size, TINY_S.img_size, seed=43)
+    # tube masks: one spatial pattern per clip, repeated over the frames, half of the patches visible
+    g = torch.Generator().manual_seed(44)
+    frame_mask = torch.stack([torch.randperm(N, generator=g) >= N // 2 for _ in range(B)])          # (B, N) True = masked
+    mask = frame_mask[:, None, :].expand(B, T, N).reshape(B, T * N).contiguous()
+    n_source = 2
+    lo, hi = (0, n_source) if which == "source" else (n_source, B)
+    rt = s.runtime()
+    rt.fp.accumulate = False
+    loss = stage1_step(s, t, vid.to(DEV), n_source, 0.5, 'tube', mask.to(DEV), which, StepState(), clip_input_resolution=TINY_T.input_resolution)
+    loss.backward()
+    ssd_g = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+    ref, *_ = O.stage1_loss(ssd_g, tsd, vid[lo:hi], mask[lo:hi], TINY_S, TINY_T)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item())
+    for k, p in s.named_parameters():
+        assert rel_l2(p.grad.cpu(), ssd_g[k].grad) <= 5e-2, k
+
+
 def test_train_one_epoch_synthetic():
     """The drop-in engine on a synthetic loader: attention-guided masks, 6 steps, loss goes down, meters come back."""
     import unite_amd
