@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time GEMM shapes under the library's env switches (one process per setting):
-   python tools/gemm_time.py "M,N,K[,f32][,bias][,qgelu][,res]" ...   -> us per launch (median of 3 x 20 launches)"""
+   python tools/gemm_time.py "M,N,K[,f32][,bias][,qgelu|gelu|dgelu][,res][,nt]" ...   -> us per launch (median of 3 x 20 launches)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,8 +15,12 @@ for spec in sys.argv[1:]:
     out = torch.empty(M, N, dtype=torch.float32 if "f32" in opts else torch.bfloat16, device="cuda")
     bias = torch.randn(N, device="cuda") if "bias" in opts else None
     res = torch.randn(M, N, device="cuda") if "res" in opts else None
-    act = ops.ACT_QUICKGELU if "qgelu" in opts else ops.ACT_NONE
-    run = lambda: ops.gemm(a, b, out, bias=bias, act=act, residual=res)
+    act = ops.ACT_QUICKGELU if "qgelu" in opts else ops.ACT_GELU if "gelu" in opts else ops.ACT_DGELU if "dgelu" in opts else ops.ACT_NONE
+    aux = torch.randn(M, N, device="cuda").to(torch.bfloat16) if ("gelu" in opts or "dgelu" in opts) else None
+    if "nt" in opts:                                   # B stored [K, N] (input-gradient layout)
+        b = b.t().contiguous()
+    run = lambda: ops.gemm(a, b, out, bias=bias, act=act, residual=res, trans_b="nt" in opts,
+                           aux_out=aux if act == ops.ACT_GELU else None, aux_in=aux if act == ops.ACT_DGELU else None)
     for _ in range(5):
         run()
     ts = []
