@@ -68,3 +68,27 @@ def test_grad_reducer_world2_gloo():
         p.join(100)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(world)) == [0, 1]
+
+
+def test_bucket_layout_keeps_the_last_bucket_small():
+    """ViT-B-like layout (a decoder block, 12 layers of 7.08 M parameters, a small patch-embed layer, in backward completion order):
+    64-MiB buckets over whole layers, and the layers that finish last split off into a tail bucket of at most 32 MiB -- the one
+    all-reduce that cannot overlap any backward work."""
+    from unite_amd.ddp import GradReducer
+    L, dec, pe = 7_087_872, 2_400_000, 600_000
+    sizes = [("clip_decoder", dec)] + [(i, L) for i in reversed(range(12))] + [("patch_embed", pe)]
+    total = sum(n for _, n in sizes)
+    tags, hi = [], total
+    for t, n in sizes:                       # forward order in memory = reverse of completion order: completion walks down
+        tags.append((t, hi - n, hi))
+        hi -= n
+    red = GradReducer(torch.zeros(1), tags, bucket_bytes=64 << 20)       # (layout only: world size 1, nothing is launched)
+    layout = [[p[0] for p in b["parts"]] for b in red.buckets]
+    assert layout[-1] == [0, "patch_embed"]
+    assert all((b["hi"] - b["lo"]) * 4 <= (96 << 20) for b in red.buckets) and (red.buckets[-1]["hi"] - red.buckets[-1]["lo"]) * 4 <= (32 << 20)
+    covered = sorted((b["lo"], b["hi"]) for b in red.buckets)             # buckets tile the buffer exactly once
+    assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert sorted([t for b in red.buckets for t in b["tags"]], key=str) == sorted([t for t, _ in sizes], key=str)
+    # no tail split when asked not to
+    red2 = GradReducer(torch.zeros(1), tags, bucket_bytes=64 << 20, tail_bytes=0)
+    assert [[p[0] for p in b["parts"]] for b in red2.buckets][-2:] == [[2, 1, 0], ["patch_embed"]]

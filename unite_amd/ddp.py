@@ -6,7 +6,8 @@ buffer covering whole layers -- is all-reduced on a side HIP stream as soon as t
 gradients, so communication overlaps the remaining backward.  There are no packing copies (the buckets ARE the
 gradient storage) and no autograd hooks (the hand-scheduled backward reports layer completion itself).
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so buckets are large
-(default 64 MiB -> 6 collectives per step for ViT-B) rather than NCCL's 25 MiB default.
+(default 64 MiB over whole layers -> 5 collectives per step for ViT-B) rather than NCCL's 25 MiB default; the layers that complete
+last (block 0 + patch embed, 29 MiB) form a bucket of their own, the only all-reduce that has no backward work left to hide under.
 
 ``GradReducer`` is device-agnostic (it only needs a flat tensor, tag -> range table and a process group), which is
 how the N > 1 path is tested with gloo on CPU.
@@ -22,21 +23,39 @@ import torch.nn as nn
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, tag_ranges: Sequence[Tuple[Hashable, int, int]], bucket_bytes: int = 64 << 20,
-                 group=None):
+                 group=None, tail_bytes: int = 32 << 20):
         """tag_ranges: (tag, start, end) element ranges in BACKWARD COMPLETION order; consecutive tags must be adjacent in
         memory (descending addresses) for them to share a bucket."""
         self.grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # The all-reduce of whatever completes LAST cannot hide under any backward work (nothing is left to compute): the layers
+        # that finish last (at most `tail_bytes` of gradients, at least one layer) get a bucket of their own, so that everything
+        # before them is already being reduced while they are still in their backward.
+        parts = list(tag_ranges)
+        n_tail, size = 0, 0
+        if tail_bytes and len(parts) > 1:
+            for tag, lo, hi in reversed(parts):
+                if n_tail and size + (hi - lo) * 4 > tail_bytes:
+                    break
+                n_tail, size = n_tail + 1, size + (hi - lo) * 4
+            if n_tail == len(parts):
+                n_tail = 0
+        head, tail = parts[:len(parts) - n_tail], parts[len(parts) - n_tail:]
         self.buckets: List[dict] = []
-        cur = None
-        for tag, lo, hi in tag_ranges:
-            if cur is not None and (lo == cur["hi"] or hi == cur["lo"]) and (cur["hi"] - cur["lo"]) * 4 < bucket_bytes:
-                cur["lo"], cur["hi"] = min(cur["lo"], lo), max(cur["hi"], hi)
-                cur["tags"].add(tag)
-            else:
-                cur = dict(lo=lo, hi=hi, tags={tag})
-                self.buckets.append(cur)
+
+        def pack(seq, cap):
+            cur = None
+            for tag, lo, hi in seq:
+                if cur is not None and (lo == cur["hi"] or hi == cur["lo"]) and (cur["hi"] - cur["lo"]) * 4 < cap:
+                    cur["lo"], cur["hi"] = min(cur["lo"], lo), max(cur["hi"], hi)
+                    cur["tags"].add(tag)
+                    cur["parts"].append((tag, lo, hi))
+                else:
+                    cur = dict(lo=lo, hi=hi, tags={tag}, parts=[(tag, lo, hi)])
+                    self.buckets.append(cur)
+        pack(head, bucket_bytes)
+        pack(tail, 1 << 62)
         self.tag_bucket: Dict[Hashable, int] = {t: i for i, b in enumerate(self.buckets) for t in b["tags"]}
         self.use_stream = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
