@@ -215,6 +215,11 @@ int unite_l2_normalize_rows(float* x, int32_t M, int32_t D, void* stream);
  * ------------------------------------------------------------------------------------ */
 int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                       int32_t BT, int32_t N, int32_t n_vis, void* stream);
+/* Stochastic-depth multipliers (timm drop_path, called at modeling_finetune.py:50,143-146; rates from
+ * modeling_adaptation.py:93): out[l*per_layer + i] = floor(keep[l] + u) / keep[l], u ~ U[0,1) from a counter-based
+ * generator keyed by (seed, element) -- the same two-valued distribution {0, 1/keep} as the reference's
+ * x.div(keep) * floor(keep + rand).  keep: device f32 [layers]; out: device f32 [layers*per_layer]. */
+int unite_drop_path_scales(const float* keep, uint64_t seed, float* out, int32_t layers, int32_t per_layer, void* stream);
 /* Same outputs from an explicit permutation (int64 [BT,N], the reference's `importance`). */
 int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                int32_t BT, int32_t N, int32_t n_vis, void* stream);

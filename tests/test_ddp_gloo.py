@@ -92,3 +92,66 @@ def test_bucket_layout_keeps_the_last_bucket_small():
     # no tail split when asked not to
     red2 = GradReducer(torch.zeros(1), tags, bucket_bytes=64 << 20, tail_bytes=0)
     assert [[p[0] for p in b["parts"]] for b in red2.buckets][-2:] == [[2, 1, 0], ["patch_embed"]]
+
+
+def _worker_accum(rank, world, port, q):
+    """update_freq = 2 (engine_for_finetuning.py:83-84) and stage 3's unused parameters (clip_decoder.* gets no gradient):
+    micro-batch 1 runs under no_sync (adds into the buffer, nothing is reduced, nothing stays pending), micro-batch 2 reduces the
+    accumulated sum once per bucket; the result equals the mean over ranks of the accumulated gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unite_amd.ddp import GradReducer
+    from unite_amd.utils import NativeScalerWithGradNormCount
+    n = 6 * 1024
+    tags = [("dec", 5 * 1024, 6 * 1024)] + [(i, i * 1024, (i + 1) * 1024) for i in reversed(range(5))]
+    grad = torch.zeros(n)
+    red = GradReducer(grad, tags, bucket_bytes=2 * 1024 * 4, tail_bytes=1024 * 4)
+    assert [sorted(map(str, b["tags"])) for b in red.buckets] == [["4", "dec"], ["2", "3"], ["1"], ["0"]]
+    g = torch.Generator().manual_seed(7 + rank)
+    micro = [torch.randn(n, generator=g) for _ in range(2)]
+    for m in micro:
+        m[5 * 1024:] = 0.0                    # the unused layer ("dec") never receives a gradient
+
+    class FakeLoss:                           # what the scaler sees: .backward() runs the hand-scheduled backward
+        def __init__(self, m):
+            self.m = m
+
+        def backward(self, create_graph=False):
+            for t, lo, hi in tags[1:]:        # "dec" never reports
+                grad[lo:hi] += self.m[lo:hi]
+                red.layer_done(t)
+
+    class FakeOpt:
+        _flat = None
+
+    scaler = NativeScalerWithGradNormCount()
+    for step in range(2):
+        grad.zero_()
+        before = red.launched
+        assert scaler(FakeLoss(micro[0]), FakeOpt(), update_grad=False, reducer=red) is None
+        assert red.launched == before and all(len(p) == len(b["tags"]) for p, b in zip(red._pending, red.buckets))
+        FakeLoss(micro[1]).backward()
+        assert red.launched == before + 3      # three buckets completed by their layers
+        red.finish()                           # ... and the bucket holding the unused layer by finish()
+        assert red.launched == before + 4
+        local = micro[0] + micro[1]
+        gathered = [torch.empty(n) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(grad, torch.stack(gathered).mean(0), atol=1e-6), (rank, step)
+    q.put(rank)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_grad_reducer_world4_accumulation_and_unused_layers_gloo():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_accum, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(100)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(world)) == [0, 1, 2, 3]

@@ -366,6 +366,48 @@ def test_teacher_fused_qkv_attention_matches_unfused(ops, BT, L, H):
     assert (o != o_ref).float().mean().item() < 0.02          # in practice bit-identical almost everywhere
 
 
+@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1)])
+def test_teacher_fused_qkv_attention_vs_fp32_reference(ops, BT, L, H):
+    """unite_teacher_qkv_attn against a plain PyTorch fp32 reference of the op it computes (reference clip.py:45-51:
+    nn.MultiheadAttention = F.linear(h, in_proj_weight, in_proj_bias) -> per-head softmax(q k^T / sqrt(64)) v), on bf16-rounded
+    inputs.  Tolerance: q, k, v are rounded to bf16 once inside the kernel (as the unfused path stores them) and the output
+    is bf16: |d| <= 2e-2 + 2e-2 |ref| on O(1) values."""
+    D = H * 64
+    hx = bf(rnd(BT * L, D, seed=L + H))
+    w = bf(rnd(3 * D, D, seed=7, scale=D ** -0.5))
+    b = rnd(3 * D, seed=8, scale=0.2)
+    qkv_ref = torch.nn.functional.linear(hx.float(), w.float(), b)
+    o_ref, _, _ = _attn_ref(qkv_ref, BT, L, H)
+    o = torch.full((BT * L, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.teacher_qkv_attn(hx.to(DEV), w.to(DEV), b.to(DEV), o, BT, L, H, 0.125)
+    assert torch.isfinite(o.float()).all()
+    torch.testing.assert_close(o.float().cpu(), o_ref, atol=2e-2, rtol=2e-2)
+    assert ((o.float().cpu() - o_ref).norm() / o_ref.norm()).item() <= 1e-2
+
+
+def test_drop_path_scales_distribution(ops):
+    """unite_drop_path_scales: every value is 0 or 1/keep (timm drop_path's two-valued multiplier), layer 0 (rate 0) is all ones,
+    the keep frequency matches keep within 4 sigma, successive seeds differ and a seed reproduces."""
+    depth, per = 12, 2 * 4096
+    rates = torch.linspace(0, 0.1, depth)
+    keep = (1.0 - rates).to(DEV)
+    out = torch.empty(depth, per, device=DEV)
+    ops.drop_path_scales(keep, 1234, out)
+    a = out.cpu()
+    assert torch.equal(a[0], torch.ones(per))
+    for l in range(1, depth):
+        k = 1.0 - rates[l].item()
+        vals = a[l].unique()
+        assert all(abs(v.item()) < 1e-12 or abs(v.item() - 1.0 / k) < 1e-6 for v in vals), (l, vals)
+        f = (a[l] > 0).float().mean().item()
+        assert abs(f - k) <= 4 * math.sqrt(k * (1 - k) / per) + 1e-9, (l, f, k)
+    out2 = torch.empty_like(out)
+    ops.drop_path_scales(keep, 1234, out2)
+    assert torch.equal(out2.cpu(), a)
+    ops.drop_path_scales(keep, 1235, out2)
+    assert not torch.equal(out2.cpu(), a)
+
+
 @pytest.mark.parametrize("N,H", [(197, 12), (257, 16), (577, 4), (5, 2)])
 def test_attn_cls_probs(ops, N, H):
     B = 5

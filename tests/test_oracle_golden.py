@@ -149,3 +149,35 @@ def test_stage1_vitb_cfg1(golden_dir):
         np.testing.assert_allclose(ssd[k].grad.norm().item(), z["gnorm." + k], rtol=2e-4, err_msg=k)
         g = ssd[k].grad.reshape(ssd[k].shape[0], -1)[:8, :8]
         np.testing.assert_allclose(g.numpy(), z["gcorner." + k], atol=1e-6, rtol=2e-3, err_msg=k)
+
+
+def test_stage1_curve_first_steps(golden_dir):
+    """The oracle's full-size stage-1 training loop (oracle step + adamw_step + grad_norm + cosine_scheduler, the bench's CPU
+    baseline) against the first steps of the loss curve the REFERENCE produced (oracle/make_golden_curve.py: its own model
+    classes, create_optimizer, get_grad_norm_, cosine_scheduler).  Bounded to 3 steps of B = 2 to keep the CPU suite short."""
+    z = _load(golden_dir, "stage1_curve.npz")
+    scfg, tcfg = O.StudentCfg(), O.TeacherCfg()
+    ssd = fill_state_dict(student_shapes(scfg), int(z["in.seed_student"]))
+    tsd = fill_state_dict(teacher_shapes(tcfg), int(z["in.seed_teacher"]))
+    B, steps = int(z["in.B"]), int(z["in.steps"])
+    lr = O.cosine_scheduler(float(z["opt.lr"]), float(z["opt.min_lr"]), 2, steps // 2, warmup_epochs=1, warmup_steps=int(z["opt.warmup_steps"]))
+    np.testing.assert_allclose(lr, z["out.lr"], rtol=1e-12)
+    m = {k: torch.zeros_like(v) for k, v in ssd.items()}
+    v = {k: torch.zeros_like(v) for k, v in ssd.items()}
+    b1, b2 = (float(b) for b in z["opt.betas"])
+    torch.set_num_threads(8)
+    for it in range(3):
+        vid = make_videos(B, 8, 224, 224, int(z["in.seed_videos0"]) + it)
+        mask = O.mask_from_importance(make_importance(B * 8, 196, int(z["in.seed_importance0"]) + it), 40, B)
+        leaf = {k: p.requires_grad_(True) for k, p in ssd.items()}
+        loss, *_ = O.stage1_loss(leaf, tsd, vid, mask, scfg, tcfg)
+        loss.backward()
+        gn = O.grad_norm([p.grad for p in leaf.values()])
+        np.testing.assert_allclose(loss.item(), z["out.loss"][it], rtol=2e-5)
+        np.testing.assert_allclose(gn.item(), z["out.grad_norm"][it], rtol=2e-4)
+        with torch.no_grad():
+            for k, p in leaf.items():
+                p.requires_grad_(False)
+                # no-decay group: 1-D tensors, .bias, and no_weight_decay() names (optim_factory.py:76-118)
+                O.adamw_step(p, p.grad, m[k], v[k], it + 1, float(lr[it]), b1, b2, float(z["opt.eps"]), float(z["opt.wd"]) if p.ndim > 1 else 0.0)
+                p.grad = None

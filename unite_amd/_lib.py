@@ -69,6 +69,7 @@ SIGNATURES = {
     "unite_clip_embed_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "unite_l2_normalize_rows": (c_i, [c_p, c_i, c_i, c_p]),
     "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_drop_path_scales": (c_i, [c_p, c_u64, c_p, c_i, c_i, c_p]),
     "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_mask_to_tokens": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_greedy_masks": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

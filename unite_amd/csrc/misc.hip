@@ -152,6 +152,20 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------ stochastic depth keep-vectors
+// timm drop_path as the blocks use it (reference modeling_finetune.py:42-53): per residual branch and sample the multiplier
+// floor(keep + U[0,1)) / keep.  out[l * per_layer + i] for layer l with keep probability keep[l]; counter-based uniforms
+// (splitmix64 of seed and element index), so no generator state lives on the device and nothing syncs with the host.
+__global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __restrict__ keep, uint64_t seed, float* __restrict__ out,
+                                                               int per_layer, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float k = keep[i / per_layer];
+    const uint64_t h = splitmix64(seed ^ splitmix64(0xD809A7ull + (uint64_t)i));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);      // [0,1)
+    out[i] = floorf(k + u) / k;
+}
+
 // ------------------------------------------------------------------------------------ stage 3: greedy committee masks
 // utils.get_greedy_masks (reference src/utils.py:89-120): per frame sort the attention descending; committee member i keeps
 // ranks i, i+k, i+2k, ... (its first n_vis of them).  One workgroup per frame, rank by counting (ties: lower index first).
@@ -608,6 +622,14 @@ extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* m
     if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
     hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const int64_t*)nullptr,
                        (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_drop_path_scales(const float* keep, uint64_t seed, float* out, int32_t layers, int32_t per_layer, void* stream) {
+    if (!keep || !out || layers <= 0 || per_layer <= 0) return UNITE_EINVAL;
+    const int total = layers * per_layer;
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, seed, out, per_layer, total);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -14,6 +14,7 @@ how the N > 1 path is tested with gloo on CPU.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Hashable, List, Optional, Sequence, Tuple
 
 import torch
@@ -62,18 +63,43 @@ class GradReducer:
         # RCCL ('nccl') averages in the collective; gloo (CPU tests, single-GPU rehearsal) has no AVG: sum, then scale
         self.native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._pending: List[set] = []
+        self._events: List[list] = []
         self._works = []
+        # False inside no_sync(): a micro-batch of a gradient-accumulation step only ADDS to the flat buffer; nothing is reduced
+        # until the backward of the last micro-batch (reference: update_freq, engine_for_finetuning.py:83-84 -- there DDP
+        # all-reduces every micro-batch; reducing the accumulated sum once is the same mean at 1 / update_freq of the traffic)
+        self.enabled = True
+        self.launched = 0                # collectives issued since construction (tests / diagnostics)
         self.reset()
 
     def reset(self):
         self._pending = [set(b["tags"]) for b in self.buckets]
+        self._events = [[] for _ in self.buckets]
         self._works = []
 
-    def layer_done(self, tag):
-        """called by the backward when every gradient of `tag` has been written (on the current stream)."""
+    @contextlib.contextmanager
+    def no_sync(self):
+        old, self.enabled = self.enabled, False
+        try:
+            yield
+        finally:
+            self.enabled = old
+
+    def layer_done(self, tag, events=None):
+        """called by the backward when every gradient of `tag` has been written: by default on the current stream; `events`
+        (HIP events, one per stream that wrote gradients of the layer) when its weight gradients ran on a side stream -- the
+        collective then waits for exactly those events instead of for whatever the main stream does next."""
+        if not self.enabled:
+            return
         i = self.tag_bucket.get(tag)
         if i is None:
             return
+        if self.use_stream and self.world > 1:
+            if events is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                events = (ev,)
+            self._events[i].extend(events)
         self._pending[i].discard(tag)
         if not self._pending[i]:
             self._launch(i)
@@ -83,21 +109,32 @@ class GradReducer:
             return
         b = self.buckets[i]
         view = self.grad[b["lo"]:b["hi"]]
+        self.launched += 1
         if self.use_stream and self.native_avg:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.stream.wait_event(ev)
+            for ev in self._events[i]:
+                self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
         else:
+            if self.use_stream:          # gloo on device tensors stages through the host from the CURRENT stream
+                for ev in self._events[i]:
+                    torch.cuda.current_stream().wait_event(ev)
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # gloo has no AVG
             self._works.append((w, view))
+        self._events[i] = []
 
     def finish(self):
         """join: every bucket reduced and visible to the current stream (call before grad-norm / optimizer)."""
+        if not self.enabled:
+            self.reset()
+            return
         for i, p in enumerate(self._pending):
             if p:            # a layer never reported (e.g. unused parameters): reduce what is there
                 self._pending[i] = set()
+                if self.use_stream and self.world > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    self._events[i].append(ev)
                 self._launch(i)
         if self.use_stream and self.native_avg:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -109,7 +146,8 @@ class GradReducer:
 
 
 def student_tag_ranges(rt) -> List[Tuple[Hashable, int, int]]:
-    """Backward completion order of the student's parameter layers with their flat ranges."""
+    """Backward completion order of the stage-1/3 student's parameter layers with their flat ranges
+    (= _StudentRuntime.tag_ranges(); kept as a function for callers that hold a runtime)."""
     fp = rt.fp
     tags: List[Tuple[Hashable, str]] = [("clip_decoder", "clip_decoder.")]
     depth = rt.depth
@@ -138,8 +176,14 @@ class DistributedDataParallel(nn.Module):
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
             dist.broadcast(rt.fp.param, src=0, group=process_group)      # run_stage1.py:809 broadcasts rank 0's weights
             rt.fp.sync_shadow()
-        self.reducer = GradReducer(rt.fp.grad, student_tag_ranges(rt), bucket_cap_mb << 20, process_group)
+        # every runtime lists its own layers in backward-completion order (stage 1/3 student: decoders, norm, blocks, patch
+        # embed; stage-2 classifier: head + fc_norm, blocks, patch embed)
+        self.reducer = GradReducer(rt.fp.grad, rt.tag_ranges(), bucket_cap_mb << 20, process_group)
         rt.layer_done_hook = self.reducer.layer_done
+
+    def no_sync(self):
+        """torch DDP's context manager: backward passes inside only accumulate into the flat gradient buffer."""
+        return self.reducer.no_sync()
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

@@ -245,6 +245,11 @@ class _StudentRuntime:
         self.layer_done_hook = None      # set by the data-parallel reducer
         self.frame_tokens = (enc.patch_embed.img_size[0] // enc.patch_embed.patch_size[0]) ** 2
 
+    def tag_ranges(self):
+        """(tag, start, end) flat-buffer ranges of the parameter layers in backward-completion order (ddp.GradReducer)."""
+        from .ddp import student_tag_ranges
+        return student_tag_ranges(self)
+
     # -- mask -> token list (device sync: the number of visible tokens has to reach the host, as in x[~mask] of the reference)
     def tokens_from_mask(self, mask: torch.Tensor):
         B, L = mask.shape
@@ -392,9 +397,9 @@ class _StudentRuntime:
         def hook(li, dx_in, scale, dxsum):
             return tap_grad(li, dx_in, scale, dxsum)
 
-        def done(i):
+        def done(i, events=None):
             if self.layer_done_hook is not None:
-                self.layer_done_hook(i)
+                self.layer_done_hook(i, events)
 
         dx0, dx0b = r.blocks_backward(dx, dxb, ctx["n_blocks"], tap_layers=set(self.taps), tap_hook=hook, layer_done=done)
         r.embed_backward(dx0b)

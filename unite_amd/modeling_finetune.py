@@ -122,6 +122,19 @@ class _VitRuntime:
         self.g_head_w, self.g_head_b = fp.g("head.weight"), fp.g("head.bias")
         self.layer_done_hook = None
 
+    def tag_ranges(self):
+        """(tag, start, end) flat-buffer ranges in backward-completion order: head + fc_norm, blocks depth-1 .. 0, patch embed
+        (flat order = named_parameters() order: patch_embed, blocks.*, fc_norm, head)."""
+        fp = self.fp
+        (nlo, _), (_, hhi) = fp.layer_ranges(["fc_norm.", "head."])
+        out = [("head", nlo, hhi)]
+        for i in reversed(range(self.depth)):
+            (lo, hi), = fp.layer_ranges([f"blocks.{i}."])
+            out.append((i, lo, hi))
+        (lo, hi), = fp.layer_ranges(["patch_embed."])
+        out.append(("patch_embed", lo, hi))
+        return out
+
     def forward_logits(self, videos, training):
         fp, r, ws = self.fp, self.runner, self.ws
         fp.refresh_if_stale()
@@ -165,7 +178,7 @@ class _VitRuntime:
         scale = None if c["dp"] is None else c["dp"][last, 1]
         ops.scale_cast_colsum(dx, dxb, r._blk[last]["g:mlp.fc2.bias"], ws.bytes_("cs.ws", ops.colsum_workspace(M, max(r.Hd, 3 * D))),
                               row_scale=scale, rows_per_scale=N, accumulate=acc)
-        done = (lambda i: self.layer_done_hook(i)) if self.layer_done_hook is not None else None
+        done = (lambda i, events=None: self.layer_done_hook(i, events)) if self.layer_done_hook is not None else None
         dx0, dx0b = r.blocks_backward(dx, dxb, self.depth, layer_done=done)
         r.embed_backward(dx0b)
         if self.layer_done_hook is not None:

@@ -270,6 +270,17 @@ def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int, vis_rows_cls=N
                                      BT, N, n_vis, _stream()), "unite_mask_sample")
 
 
+def drop_path_scales(keep, seed: int, out):
+    """out (layers, ...) f32 <- floor(keep[l] + u) / keep[l] (timm drop_path multipliers); keep: device f32 [layers]."""
+    lib = _lib.load()
+    _req(keep, F32, "keep"); _req(out, F32, "out")
+    layers = keep.numel()
+    assert out.is_contiguous() and out.numel() % layers == 0
+    _lib.check(lib.unite_drop_path_scales(_ptr(keep), seed & 0xFFFFFFFFFFFFFFFF, _ptr(out), layers, out.numel() // layers, _stream()),
+               "unite_drop_path_scales")
+    return out
+
+
 def mask_from_importance(importance, mask, vis_tokens, n_vis: int, vis_rows_cls=None):
     lib = _lib.load()
     BT, N = importance.shape

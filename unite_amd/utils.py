@@ -33,6 +33,13 @@ class NativeScalerWithGradNormCount:
         self._ws = None
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True, reducer=None):
+        if reducer is not None and not update_grad:
+            # a micro-batch of an accumulation step (update_freq > 1): gradients only add up in the flat buffer; the reducer
+            # stays quiet until the backward of the last micro-batch, which reduces the accumulated sum once
+            with reducer.no_sync():
+                loss.backward(create_graph=create_graph)
+            reducer.reset()
+            return None
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None

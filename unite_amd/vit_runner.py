@@ -131,10 +131,11 @@ class ViTRunner:
         if not training or max(self.dp_rates) == 0.0:
             return None
         if getattr(self, "_keep", None) is None:        # uploaded once: a host -> device copy here would block the host every step
-            self._keep = (1.0 - torch.tensor(self.dp_rates, dtype=F32)).view(-1, 1, 1).to(self.fp.device)
-        keep = self._keep
-        u = torch.rand(self.depth, 2, B, dtype=F32, device=self.fp.device)
-        return torch.floor(keep + u) / keep
+            self._keep = (1.0 - torch.tensor(self.dp_rates, dtype=F32)).to(self.fp.device)
+            self._dp_seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF      # follows torch.manual_seed(seed + rank)
+        self._dp_seed = (self._dp_seed + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+        out = self.ws.get("dp.scales", (self.depth, 2, B), F32)
+        return ops.drop_path_scales(self._keep, self._dp_seed, out)
 
     # ------------------------------------------------------------------ forward
     def embed(self, videos: torch.Tensor, tokens: Optional[torch.Tensor], M: int) -> torch.Tensor:
@@ -227,11 +228,22 @@ class ViTRunner:
                 ev_fn()
 
         def retire(j):
-            """block j's parameter gradients are complete on the main stream's timeline -> report it"""
+            """the main stream may overwrite the parity buffers block j's side-stream work read"""
             if side is not None and j in done_ev:
                 main.wait_event(done_ev.pop(j))
-            if layer_done is not None:
+
+        def report(j):
+            """every gradient of block j is written: the side stream's part at done_ev[j], the main stream's part (LayerNorm
+            gamma / beta, bias column sums) by now.  The reducer's collective waits for exactly these two events, so a bucket
+            can start as soon as its last layer's weight gradients finish, not when the main stream next meets them."""
+            if layer_done is None:
+                return
+            if side is None:
                 layer_done(j)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            layer_done(j, (ev, done_ev[j]))
 
         for i in reversed(range(n_blocks)):
             w, s = self._blk[i], self.saved[i]
@@ -295,8 +307,7 @@ class ViTRunner:
             dx, dxb = dx0, dx0b
             if tapped:
                 dx, dxb = tap_hook(i - 1, dx, nxt_scale, nxt_bias_g)
-            if side is None and layer_done is not None:
-                layer_done(i)
+            report(i)
         if side is not None:
             for j in sorted(done_ev, reverse=True):
                 retire(j)
