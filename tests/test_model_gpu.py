@@ -186,15 +186,21 @@ def test_student_tiny_vs_reference_golden(golden_dir):
         opt.zero_grad()
         l = s.forward_loss(vid, vis, nv, tgt.reshape(K * B * n_vis, C))
         gn = scaler(l, opt, clip_grad=None, parameters=s.parameters())
-        assert abs(l.item() - z["out.losses3"][it]) <= 5e-3 * z["out.losses3"][it], (it, l.item(), z["out.losses3"][it])
-        assert abs(gn.item() - z["out.gnorms3"][it]) <= 5e-2 * z["out.gnorms3"][it], (it, gn.item(), z["out.gnorms3"][it])
+        assert abs(l.item() - z["out.losses3"][it]) <= 1e-3 * z["out.losses3"][it], (it, l.item(), z["out.losses3"][it])      # measured <= 6e-4
+        assert abs(gn.item() - z["out.gnorms3"][it]) <= 1e-2 * z["out.gnorms3"][it], (it, gn.item(), z["out.gnorms3"][it])  # measured <= 1e-3
     sd = s.state_dict()
+    lr = float(z["opt.lr"])
     for k in [f[len("after3."):] for f in z if f.startswith("after3.")]:
-        a, r = sd[k].cpu(), torch.from_numpy(z["after3." + k])
-        # Adam normalises the step: an element whose gradient is ~0 moves by up to lr per step in EITHER direction whatever
-        # the rounding, so two correct trajectories can differ by 2*3*lr at isolated elements; the mean pins the rest.
-        assert (a - r).abs().max() <= 6.2 * float(z["opt.lr"]), k
-        assert (a - r).abs().mean() <= 0.1 * float(z["opt.lr"]), (k, (a - r).abs().mean())
+        a, r, g1 = sd[k].cpu(), torch.from_numpy(z["after3." + k]), torch.from_numpy(z["g." + k])
+        d = (a - r).abs()
+        # Adam normalises the step, so an element whose gradient is ~0 moves by up to lr per step in EITHER direction whatever the
+        # rounding: only elements with a resolved gradient pin the update rule.  Where |g_ref| >= rms(g_ref) (the first step's
+        # gradient; a third of the elements) the trajectory is held to 0.1 lr after three steps (measured <= 0.07 lr; a wrong
+        # bias correction moves EVERY element by >= 0.5 lr at step 1), and the mean over all elements to 0.05 lr (measured 0.03).
+        strong = g1.abs() >= g1.pow(2).mean().sqrt()
+        assert strong.float().mean() > 0.15, k
+        assert d[strong].max() <= 0.1 * lr, (k, (d[strong].max() / lr).item())
+        assert d.mean() <= 0.05 * lr, (k, (d.mean() / lr).item())
 
 
 def test_drop_path_and_accumulation_tiny(golden_dir):

@@ -25,6 +25,7 @@ class NativeScalerWithGradNormCount:
     """Same call signature and state_dict()['scale'] as the reference (utils.py:602-628).  The kernels compute in
     bf16 operands / fp32 accumulation, so there is no loss scaling: scale is the constant 1.0 (SURVEY A-17)."""
     state_dict_key = "amp_scaler"
+    RING = 256
 
     def __init__(self):
         self._scale = 1.0
@@ -55,11 +56,16 @@ class NativeScalerWithGradNormCount:
     def grad_norm(self, flat, clip_grad=None):
         dev = flat.grad.device
         if self._norm is None:
-            self._norm = torch.zeros(1, device=dev)
+            # a ring of result slots: the engines keep the returned 0-dim tensors un-read until the next log line (no host sync per
+            # step), so consecutive steps must not write the same element
+            self._norm = torch.zeros(self.RING, device=dev)
+            self._slot = 0
             self._coef = torch.ones(1, device=dev)
             self._ws = torch.empty(ops.grad_norm_workspace(flat.grad.numel()), dtype=torch.uint8, device=dev)
-        ops.grad_norm_flat(flat.grad, self._norm, self._ws, max_norm=float(clip_grad or 0.0), clip_coef_out=self._coef)
-        return self._norm[0]                          # 0-dim device tensor: no host sync here
+        self._slot = (self._slot + 1) % self.RING
+        out = self._norm[self._slot:self._slot + 1]
+        ops.grad_norm_flat(flat.grad, out, self._ws, max_norm=float(clip_grad or 0.0), clip_coef_out=self._coef)
+        return out[0]                                 # 0-dim device tensor: no host sync here
 
     def state_dict(self):
         return {"scale": self._scale}
