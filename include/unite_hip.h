@@ -82,6 +82,13 @@ size_t unite_gemm_colsum_workspace(int32_t M, int32_t N);
 
 int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
 
+/* Kernel selection knob (diagnostics, tests, A/B runs inside one process): which products take the persistent 256 x 128
+ * kernel (gemm_pp.hip: the epilogue of a tile runs under the main loop of the workgroup's next tile; needs A k-contiguous,
+ * K % 64 == 0, K >= 768) instead of the tile kernels.  0 never, 1 the shapes it measured faster on (default), 2 whenever it
+ * supports the problem, -1 back to the UNITE_GEMM_PP environment variable.  Results are the same either way (f32 accumulation
+ * in K order inside a K-tile; integer-valued products are bit-exact on both). */
+int unite_gemm_set_policy(int32_t persistent);
+
 /* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
  * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117
  * under autograd) fill the chip together instead of each needing split-K slabs.  Results are identical to `count`

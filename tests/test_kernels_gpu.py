@@ -179,6 +179,97 @@ def test_gemm_fused_column_sums(ops, M, N, K, f32):
     assert torch.equal(cs3, cs)                                         # deterministic
 
 
+# ---- persistent 256 x 128 kernel (gemm_pp.hip: K a multiple of 64 and >= 768, A k-contiguous): the epilogue of a tile runs under
+# the main loop of the workgroup's next tile, so the cases below include grids where a workgroup owns 1, 2 and 3 tiles
+@pytest.fixture
+def persistent_everywhere():
+    """route every supported product to the persistent kernel (by default only the shapes it measured faster on take it)"""
+    from unite_amd import _lib
+    lib = _lib.load()
+    assert lib.unite_gemm_set_policy(2) == 0
+    yield
+    assert lib.unite_gemm_set_policy(-1) == 0
+
+
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(520, 768, 768), (808, 392, 832), (10240, 1152, 768), (5000, 2304, 1024), (256, 128, 3072)])
+def test_gemm_persistent_exact_integers(ops, persistent_everywhere, tb, M, N, K):
+    """small-integer operands: every product and partial sum is exact in f32 -> the f32 output is bit-exact against the f64 product;
+    the bf16 output equals the exact product rounded once.  Ragged M and N (N only for the k-contiguous B), 1 to 3 tiles per workgroup."""
+    if tb and N % 128:
+        pytest.skip("k-strided B takes the persistent kernel for N % 128 == 0 only (other shapes: tile kernels, covered above)")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = (a.double() @ b.double().t()).float()
+    a_d, b_d = bf(a).to(DEV), bf(b.t().contiguous() if tb else b).to(DEV)
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a_d, b_d, out16, trans_b=tb)
+    assert torch.equal(out16.cpu(), ref.to(torch.bfloat16))
+    if not tb:
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm(a_d, b_d, out)
+        assert torch.equal(out.cpu(), ref)
+        bias = torch.randint(-9, 10, (N,), generator=g).float()
+        res = torch.randint(-50, 51, (M, N), generator=g).float()
+        ops.gemm(a_d, b_d, out, bias=bias.to(DEV), residual=res.to(DEV))
+        assert torch.equal(out.cpu(), ref + bias + res)
+
+
+def test_gemm_persistent_epilogues(ops, persistent_everywhere):
+    """every epilogue the persistent kernel implements, against a PyTorch fp32 reference on bf16-rounded operands, at a shape where
+    workgroups own two tiles (the second tile's main loop hides the first one's epilogue) and the edges are ragged."""
+    M, N, K = 10240 + 72, 1152 + 40, 768
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    acc = a.float() @ w.float().t() + bias
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ad, wd, out, bias=bd, act=ops.ACT_GELU, aux_out=z)
+    torch.testing.assert_close(z.float().cpu(), acc, atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(out.float().cpu(), O.gelu_erf(acc), atol=2e-2, rtol=1e-2)
+    out.fill_(float("nan"))
+    ops.gemm(ad, wd, out, bias=bd, act=ops.ACT_QUICKGELU)
+    torch.testing.assert_close(out.float().cpu(), O.quick_gelu(acc), atol=2e-2, rtol=1e-2)
+    out.fill_(float("nan"))
+    ops.gemm(ad, wd, out, bias=bd)
+    torch.testing.assert_close(out.float().cpu(), acc, atol=2e-2, rtol=1e-2)
+    # stochastic-depth row scale + residual, f32 out, a strided output view
+    res = rnd(M, N, seed=5)
+    rows_per = 322
+    rs = torch.tensor([0.0 if i % 3 == 0 else 1.0 / 0.9 for i in range((M + rows_per - 1) // rows_per)])
+    big = torch.full((M, N + 8), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, big[:, 8:], bias=bd, row_scale=rs.to(DEV), rows_per_scale=rows_per, residual=res.to(DEV))
+    ref = res + acc * rs.repeat_interleave(rows_per)[:M, None]
+    torch.testing.assert_close(big[:, 8:].cpu(), ref, atol=2e-4, rtol=1e-4)
+    assert torch.isnan(big[:, :8]).all()
+    # GELU' with the saved pre-activations, k-strided B (the fc2 input gradient), N a multiple of 128
+    N2 = 1152
+    w2 = bf(rnd(K, N2, seed=6, scale=K ** -0.5))
+    zz = bf(rnd(M, N2, seed=4))
+    zg = zz.float().clone().requires_grad_(True)
+    O.gelu_erf(zg).sum().backward()
+    out2 = torch.full((M, N2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(ad, w2.to(DEV), out2, trans_b=True, act=ops.ACT_DGELU, aux_in=zz.to(DEV))
+    torch.testing.assert_close(out2.float().cpu(), (a.float() @ w2.float()) * zg.grad, atol=2e-2, rtol=1e-2)
+
+
+def test_gemm_persistent_matches_tile_kernels(ops, persistent_everywhere):
+    """the teacher's c_fc shape (M = 50 432: 4 728 tiles, 18-19 per workgroup) against the same product in four row chunks that are too
+    small for the persistent kernel's planner threshold... both paths accumulate k in the same order within a K-tile; allow one bf16 ulp."""
+    M, N, K = 50432, 3072, 768
+    a = bf(rnd(M, K, seed=11)).to(DEV)
+    w = bf(rnd(N, K, seed=12, scale=K ** -0.5)).to(DEV)
+    bias = rnd(N, seed=13).to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, w, out, bias=bias, act=ops.ACT_QUICKGELU)
+    rows = torch.randint(0, M, (512,), generator=torch.Generator().manual_seed(14))
+    ref = O.quick_gelu(a[rows.to(DEV)].float() @ w.float().t() + bias).cpu()
+    torch.testing.assert_close(out[rows.to(DEV)].float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    assert torch.isfinite(out.float()).all()
+
+
 def test_gemm_rejects_bad_arguments(ops):
     from unite_amd._lib import UniteHipError
     a = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)      # K = 12: rows are not 16-byte multiples

@@ -23,10 +23,23 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def gemm_case(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, **kw):
+def gemm_case(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, epi="", **kw):
+    """epi: the epilogue of the step's launch of this shape -- "bias", "gelu" (bias + GELU + saved pre-activation), "qgelu", "dgelu",
+    "res" (bias + stochastic-depth row scale + f32 residual)"""
     a = torch.randn((K, M) if ta else (M, K), device=DEV).to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device=DEV).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=out_dtype, device=DEV)
+    if epi in ("bias", "gelu", "qgelu", "res"):
+        kw["bias"] = torch.randn(N, device=DEV)
+    if epi == "gelu":
+        kw.update(act=ops.ACT_GELU, aux_out=torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    if epi == "qgelu":
+        kw.update(act=ops.ACT_QUICKGELU)
+    if epi == "dgelu":
+        kw.update(act=ops.ACT_DGELU, aux_in=torch.randn(M, N, device=DEV).to(torch.bfloat16))
+    if epi == "res":
+        kw.update(residual=torch.randn(M, N, device=DEV), row_scale=torch.ones((M + 319) // 320, device=DEV), rows_per_scale=320)
+    name = f"{name} [{epi}]" if epi else name
     if ta and tb:
         kw["workspace"] = WS
     t = timeit(lambda: ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw))
@@ -38,24 +51,27 @@ def gemm_case(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, **kw)
 def main():
     Ms, Mt = 10240, 50432
     print("== GEMM, student (M = 32*320)")
-    gemm_case("qkv fwd", Ms, 2304, 768)
-    gemm_case("proj fwd (f32 out)", Ms, 768, 768, out_dtype=torch.float32)
-    gemm_case("fc1 fwd", Ms, 3072, 768)
-    gemm_case("fc2 fwd (f32 out)", Ms, 768, 3072, out_dtype=torch.float32)
-    gemm_case("fc2 dgrad (NN)", Ms, 3072, 768, tb=True)
+    gemm_case("qkv fwd", Ms, 2304, 768, epi="bias")
+    gemm_case("proj fwd (f32 out)", Ms, 768, 768, out_dtype=torch.float32, epi="res")
+    gemm_case("fc1 fwd", Ms, 3072, 768, epi="gelu")
+    gemm_case("fc2 fwd (f32 out)", Ms, 768, 3072, out_dtype=torch.float32, epi="res")
+    gemm_case("fc2 dgrad (NN)", Ms, 3072, 768, tb=True, epi="dgelu")
     gemm_case("fc1 dgrad (NN)", Ms, 768, 3072, tb=True)
+    gemm_case("proj dgrad (NN)", Ms, 768, 768, tb=True)
     gemm_case("qkv dgrad (NN)", Ms, 768, 2304, tb=True)
     gemm_case("fc1 wgrad (TN, f32)", 3072, 768, Ms, ta=True, tb=True, out_dtype=torch.float32)
     gemm_case("fc2 wgrad (TN, f32)", 768, 3072, Ms, ta=True, tb=True, out_dtype=torch.float32)
     gemm_case("qkv wgrad (TN, f32)", 2304, 768, Ms, ta=True, tb=True, out_dtype=torch.float32)
     gemm_case("proj wgrad (TN, f32)", 768, 768, Ms, ta=True, tb=True, out_dtype=torch.float32)
     print("== GEMM, teacher (M = 256*197)")
-    gemm_case("qkv", Mt, 2304, 768)
-    gemm_case("out_proj (f32)", Mt, 768, 768, out_dtype=torch.float32)
-    gemm_case("c_fc", Mt, 3072, 768)
-    gemm_case("c_proj (f32)", Mt, 768, 3072, out_dtype=torch.float32)
+    gemm_case("qkv", Mt, 2304, 768, epi="bias")
+    gemm_case("out_proj (f32)", Mt, 768, 768, out_dtype=torch.float32, epi="res")
+    gemm_case("c_fc", Mt, 3072, 768, epi="qgelu")
+    gemm_case("c_proj (f32)", Mt, 768, 3072, out_dtype=torch.float32, epi="res")
     gemm_case("square 4096", 4096, 4096, 4096)
     gemm_case("square 8192", 8192, 8192, 8192)
+    if os.environ.get("GEMM_ONLY"):
+        return
     print("== attention")
     for (B, N, H, nm) in [(32, 320, 12, "student"), (256, 197, 12, "teacher")]:
         qkv = torch.randn(B * N, 3 * H * 64, device=DEV).to(torch.bfloat16)

@@ -909,6 +909,22 @@ extern "C" int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t coun
     return UNITE_OK;
 }
 
+// gemm_pp.hip: persistent 256 x 128 kernel with the epilogue of one tile hidden under the main loop of the next
+namespace {
+int g_pp_policy = -1;      // -1: UNITE_GEMM_PP (default 1); set by unite_gemm_set_policy (tests / A-B runs in one process)
+int g_pp_env() {
+    static const int v = getenv("UNITE_GEMM_PP") ? atoi(getenv("UNITE_GEMM_PP")) : 1;
+    return v;
+}
+}  // namespace
+extern "C" int unite_gemm_set_policy(int32_t persistent) {
+    if (persistent < -1 || persistent > 2) return UNITE_EINVAL;
+    g_pp_policy = persistent;
+    return UNITE_OK;
+}
+int unite_gemm_pp_supported(const unite_gemm_args& g);
+int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_bytes, hipStream_t s);
+
 extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     if (!args) return UNITE_EINVAL;
     const unite_gemm_args& g = *args;
@@ -916,6 +932,30 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     {
         const int rc = check_problem(g, a_bytes, b_bytes);
         if (rc != UNITE_OK) return rc;
+    }
+    {
+        // The persistent kernel (gemm_pp.hip) takes the shapes it measured faster on than the tile kernels below (MI355X, round 2,
+        // profiles/r02_kernel_microbench.txt): k-contiguous B with an f32 output at K <= 1024 (proj / out_proj / decoder heads: the residual
+        // epilogue hides under the next tile and one launch fills the chip) and the plain bf16 products of the student (qkv).  The rest --
+        // GELU / QuickGELU epilogues, K = 3072, the k-strided B of the input gradients -- is within +-5 % or slower and stays on the tile
+        // kernels.  UNITE_GEMM_PP = 0 never / 1 measured shapes (default) / 2 whenever supported; UNITE_GEMM_PP_MIN_TILES moves the size floor.
+        const int pp = g_pp_policy >= 0 ? g_pp_policy : g_pp_env();
+        static const int pp_min = getenv("UNITE_GEMM_PP_MIN_TILES") ? atoi(getenv("UNITE_GEMM_PP_MIN_TILES")) : 64;
+        static const char* force_k = getenv("UNITE_GEMM_KERNEL");
+        const bool measured = !g.trans_b && ((g.out_f32 && g.K <= 1024) ||
+                                             (!g.out_f32 && g.act == UNITE_ACT_NONE && g.K <= 1024 && (int64_t)g.M * g.N <= (int64_t)32 << 20));
+        if (pp && (pp == 2 || measured) && !force_k && ((g.M + 255) / 256) * ((g.N + 127) / 128) >= pp_min && unite_gemm_pp_supported(g)) {
+            hipStream_t s = (hipStream_t)stream;
+            const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
+            if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
+            const int rc = unite_gemm_pp_launch(g, a_bytes, b_bytes, s);
+            if (prof) {
+                (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+                g_prof.used++;
+                g_prof.flops += 2.0 * g.M * g.N * g.K;
+            }
+            return rc;
+        }
     }
     Params p;
     memset(&p, 0, sizeof(p));
