@@ -10,9 +10,13 @@ global grad-norm -> AdamW.  Inputs are resident in HBM before the timed region; 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel (gemm_bf16_kernel): algorithmic FLOPs / launch time, measured with HIP events
-                 on the launch stream in a second pass of the same steps (events off during the timed region so
-                 that `value` is undisturbed); step_mfma_frac_* put the whole step against the 2.5 PF/s bf16 peak.
+  roofline     : the dominant kernels (bf16 MFMA GEMM family + fused teacher kernel): algorithmic FLOPs / launch time,
+                 measured with HIP events on the launch stream in a second pass of the same steps (events off during
+                 the timed region so that `value` is undisturbed).  step_frac puts the whole step against the 2.5 PF/s
+                 bf16 peak (462.2 GF per clip); student_step_frac the student's part (179.7 GF per clip over
+                 student_ms = ms_per_step - teacher_ms, the number north_star's 40 % target is about); teacher_frac the
+                 frozen teacher (282.5 GF per clip over teacher_ms, its own steady-state loop).
+  host_enqueue_ms_per_step : wall time the host needs to enqueue one step (no sync inside a step).
   cpu_baseline : the CPU oracle (oracle/umt_oracle.py, fp32 torch) timed on this host's cores on a bounded sample.
 """
 import argparse
@@ -163,6 +167,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, gn = step()
+    t_enq = time.perf_counter() - t0          # the host has enqueued every launch of the timed steps (nothing synchronises inside a step)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -181,6 +186,22 @@ def main():
         teacher.runtime().two_streams = on
         state.overlap_targets = on
 
+    # the step by phase (as tools/phase_time.py): the frozen teacher alone in a steady-state loop with the same streams as the timed region;
+    # student = step - teacher (student forward / backward / AdamW; the teacher's target tail runs under the student's forward)
+    teacher_ms = None
+    if not a.no_roofline:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_t = min(a.steps, 20)
+        for _ in range(3):
+            teacher.forward_attention(videos)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(n_t):
+            teacher.forward_attention(videos)
+        ev1.record()
+        torch.cuda.synchronize()
+        teacher_ms = ev0.elapsed_time(ev1) / n_t
+
     roof = None
     if not a.no_roofline:
         set_concurrency(False)          # kernel durations of the roofline pass must not include time shared with other kernels
@@ -197,15 +218,25 @@ def main():
         lib.unite_prof_enable(0, 0)
         print(f"[bench] profiled pass: {cnt.value} MFMA-kernel launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        traffic = None      # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py), same command
-        tp = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tp):
-            traffic = round(json.load(open(tp))["traffic_bytes_per_launch"])
+        # HBM bytes per MFMA-kernel launch: NOT measured by this run (PMC counters need rocprofv3: tools/final_prof.sh collects the
+        # FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` and tools/pmc_traffic.py reduces them); quoted with its source, or null
+        traffic, traffic_source = None, None
+        for name in ("r02_gemm_traffic.json",):
+            tp = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tp):
+                tj = json.load(open(tp))
+                traffic = round(tj["traffic_bytes_per_launch"])
+                traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of bench.py --serial at commit {tj.get('commit', '?')}; not measured in this run)"
         roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM kernels: gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues) + teacher_qkv_attn_kernel (projection + attention FLOPs)", "achieved": round(ach, 1),
                 "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
+                "step_frac": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
+                "teacher_ms": round(teacher_ms, 3), "student_ms": round(ms_step - teacher_ms, 3),
+                "student_step_frac": round(B * GF_STUDENT / ((ms_step - teacher_ms) * 1e-3) / PEAK_BF16, 4),
+                "teacher_frac": round(B * GF_TEACHER / (teacher_ms * 1e-3) / PEAK_BF16, 4),
                 "note": "HIP events on the launch stream around every launch of these kernels in a second pass of the same steps, run on ONE stream "
                         "(the timed region overlaps weight-gradient GEMMs and the teacher's frame ranges on side streams, which would "
                         "charge each launch for time it shares with other kernels); same numbers as `bench.py --serial` under rocprofv3"}
@@ -224,7 +255,8 @@ def main():
                "config": {"workload": "stage1 UMT pretrain, ViT-B/16 student + CLIP-B/16 teacher, synthetic 8fx224^2 clips, "
                                       f"B={B}/GPU, mask_ratio=0.8, bf16 MFMA + fp32 accumulate/master (BASELINE configs[1])",
                           "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05"},
-               "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5)}
+               "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
+               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)}
         if roof is not None:
             out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1:
