@@ -7,7 +7,8 @@
 
 Same ``args`` fields, same key rewrites in the same order, same ``utils.load_state_dict`` (non-strict, prefix-aware) at the end.
 Host logic only (torch CPU tensors); nothing here touches the GPU path.  The reference reads checkpoints with a plain
-``torch.load`` (they carry an argparse Namespace): ``read_checkpoint`` tries the tensor-only loader first and falls back to it.
+``torch.load`` (they carry an argparse Namespace): ``read_checkpoint`` uses the tensor-only loader with that class allow-listed and
+unpickles only on an explicit opt-in.
 """
 from __future__ import annotations
 
@@ -19,13 +20,26 @@ import torch
 from . import utils
 
 
-def read_checkpoint(path: str):
+def read_checkpoint(path: str, trusted: bool = False):
+    """Tensor-only load (``weights_only=True``: nothing in the file is executed) with the one non-tensor class the reference's
+    checkpoints carry allow-listed -- an ``argparse.Namespace`` under 'args' (utils.py:700-704 saves ``args`` itself).  Files that
+    still refuse (arbitrary pickled objects) are loaded with the executing unpickler only when the caller says the file is its own
+    (``trusted``) or the user opts in with UNITE_UNSAFE_CHECKPOINT_LOAD=1: ``student_init`` / ``finetune`` / ``clip_decoder_init``
+    usually point at third-party downloads."""
+    import argparse
+    import os
     if str(path).startswith("https"):
         raise RuntimeError("remote checkpoints are not fetched (no network in this build); download the file and pass its path")
     try:
-        return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        return torch.load(path, map_location="cpu", weights_only=False)      # user-supplied file with pickled args, as the reference
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if not (trusted or os.environ.get("UNITE_UNSAFE_CHECKPOINT_LOAD", "0") == "1"):
+            raise RuntimeError(
+                f"{path}: refused by the tensor-only loader ({type(e).__name__}: {str(e).splitlines()[0][:200]}).  If you trust the file, "
+                "set UNITE_UNSAFE_CHECKPOINT_LOAD=1 to unpickle it as the reference's torch.load does (this can execute code from the file).") from e
+        print(f"WARNING: unpickling {path} with weights_only=False (it can execute code from the file)")
+        return torch.load(path, map_location="cpu", weights_only=False)
 
 
 def _select(checkpoint, model_key: str):

@@ -362,7 +362,8 @@ def load_state_dict(model, state_dict, input_resolution=224, patch_size=16, cent
 def _build(name, pretrained, center, input_resolution, **kw):
     model = VisionTransformer(input_resolution=input_resolution, **kw)
     if pretrained:
-        sd = torch.load(_MODELS[name], map_location='cpu', weights_only=True)
+        path = os.path.join(os.environ.get("UNITE_CLIP_PATH", MODEL_PATH), os.path.basename(_MODELS[name]))      # resolved at call time
+        sd = torch.load(path, map_location='cpu', weights_only=True)
         load_state_dict(model, sd, input_resolution=input_resolution, patch_size=kw["patch_size"], center=center)
     return model.eval()
 

@@ -360,7 +360,8 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
             if latest >= 0:
                 args.resume = os.path.join(output_dir, 'checkpoint-%d.pth' % latest)
     if getattr(args, "resume", ""):
-        ckpt = torch.load(args.resume, map_location='cpu', weights_only=False)   # a file this code wrote
+        from .checkpoint import read_checkpoint
+        ckpt = read_checkpoint(args.resume)       # tensor-only loader: save_model stores vars(args), tensors and plain numbers
         model_without_ddp.load_state_dict(ckpt['model'])
         if 'optimizer' in ckpt and 'epoch' in ckpt:
             optimizer.load_state_dict(ckpt['optimizer'])
