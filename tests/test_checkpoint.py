@@ -4,6 +4,7 @@ import os
 from functools import partial
 from types import SimpleNamespace
 
+import pytest
 import torch
 
 from unite_amd import checkpoint as C
@@ -122,3 +123,51 @@ def test_interpolate_pos_embed_time_then_space():
     keep = same["pos_embed"].clone()
     m2 = SimpleNamespace(pos_embed=torch.zeros(1, 8 * 16, D), patch_embed=SimpleNamespace(num_patches=8 * 16, tubelet_size=1))
     assert torch.equal(C.interpolate_pos_embed(same, m2, num_frames=8)["pos_embed"], keep)
+
+
+def test_clip_weight_inflation_and_pos_resize_vs_reference_golden(golden_dir):
+    """unite_amd.clip.inflate_weight / load_state_dict against THE REFERENCE's own functions (src/models/clip.py:191-231, imported as is by
+    oracle/make_golden_ckpt.py): 2-D conv1 weights inflated along time (center / mean) and the position table bicubic-resized from a
+    3 x 3 to a 2 x 2 grid; every other tensor loads unchanged.  Tolerance: bit-exact for the inflation, 1e-6 for the bicubic resize."""
+    import os
+    import numpy as np
+    import torch
+    from unite_amd import clip
+    z = np.load(os.path.join(golden_dir, "clip_ckpt.npz"))
+    w2d = torch.from_numpy(z["in.w2d"])
+    assert torch.equal(clip.inflate_weight(w2d, 3, center=True), torch.from_numpy(z["out.inflate_center_t3"]))
+    assert torch.equal(clip.inflate_weight(w2d, 2, center=False), torch.from_numpy(z["out.inflate_mean_t2"]))
+    for tag, center in (("c", True), ("m", False)):
+        model = clip.VisionTransformer(input_resolution=32, patch_size=16, width=64, layers=2, heads=1, output_dim=32, kernel_size=1,
+                                       return_attn=True, clip_return_layers=[1])
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for k in ("conv1.weight", "positional_embedding", "proj", "ln_pre.weight"):
+            sd[k] = torch.from_numpy(z[f"in.{tag}.{k}"])
+        clip.load_state_dict(model, sd, input_resolution=32, patch_size=16, center=center)
+        got = model.state_dict()
+        assert torch.equal(got["conv1.weight"], torch.from_numpy(z[f"out.{tag}.conv1.weight"]))
+        torch.testing.assert_close(got["positional_embedding"], torch.from_numpy(z[f"out.{tag}.positional_embedding"]), atol=1e-6, rtol=0)
+        assert torch.equal(got["proj"], torch.from_numpy(z[f"out.{tag}.proj"]))
+        assert torch.equal(got["ln_pre.weight"], torch.from_numpy(z[f"in.{tag}.ln_pre.weight"]))
+
+
+class _Payload:
+    pass
+
+
+def test_read_checkpoint_refuses_pickles_without_opt_in(tmp_path, monkeypatch):
+    """third-party checkpoint files are read with the tensor-only loader; an argparse.Namespace (what the reference saves under 'args')
+    is allow-listed, anything else needs UNITE_UNSAFE_CHECKPOINT_LOAD=1."""
+    import argparse
+    import torch
+    from unite_amd.checkpoint import read_checkpoint
+
+    ok = tmp_path / "ok.pth"
+    torch.save({"model": {"w": torch.ones(2)}, "args": argparse.Namespace(lr=1e-3), "epoch": 3}, ok)
+    ck = read_checkpoint(str(ok))
+    assert ck["epoch"] == 3 and ck["args"].lr == 1e-3
+    bad = tmp_path / "bad.pth"
+    torch.save({"model": {"w": torch.ones(2)}, "extra": _Payload()}, bad)
+    monkeypatch.delenv("UNITE_UNSAFE_CHECKPOINT_LOAD", raising=False)
+    with pytest.raises(RuntimeError, match="UNITE_UNSAFE_CHECKPOINT_LOAD"):
+        read_checkpoint(str(bad))
