@@ -298,6 +298,11 @@ int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 size_t unite_grad_norm_workspace(int64_t n);
 int unite_grad_norm_flat(const float* grad, int64_t n, float max_norm, float* norm_out, float* clip_coef_out,
                          void* workspace, void* stream);
+/* The same norm over the chunks whose optimizer group is not `skip_group` (chunk_group: uint8 per 1024 elements, the table
+ * unite_adamw_flat takes): parameters that have no gradient in this step -- frozen ones, layers that were not executed -- do not
+ * enter the norm or the clip coefficient, as torch's `p.grad is not None` filter (utils.py:631-643). */
+int unite_grad_norm_flat_masked(const float* grad, int64_t n, const uint8_t* chunk_group, int32_t skip_group, float max_norm,
+                                float* norm_out, float* clip_coef_out, void* workspace, void* stream);
 
 /* Token mean over the sequence (stage 2/3 pooling, modeling_finetune.py:376, run_stage3.py:333-338):
  * out[b,:] = mean_n x[b,n,:]  (x f32 [B,N,D], out f32 [B,D]).  Backward: dx[b,n,:] (+)= dout[b,:]/N. */

@@ -203,6 +203,55 @@ def test_student_tiny_vs_reference_golden(golden_dir):
         assert d.mean() <= 0.05 * lr, (k, (d.mean() / lr).item())
 
 
+def test_parameters_without_gradient_follow_torch_semantics():
+    """torch semantics of `p.grad is None`: (a) blocks above the highest tap are not executed under clip_only
+    (modeling_adaptation.py:165-166) -- their parameters must not be weight-decayed or moment-updated and must not enter the gradient
+    norm; (b) frozen decoders (freeze_clip_decoders, run_stage1.py:586-590: requires_grad = False) still get gradient values written by
+    the hand-scheduled backward, which must stay out of the norm and of the update.  Reference behaviour: torch.optim.AdamW skips
+    p.grad is None; utils.get_grad_norm_ (:631-643) filters on it."""
+    from functools import partial
+    from unite_amd.modeling_adaptation import AdaptationVisionTransformer
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount
+    cfg = O.StudentCfg(img_size=32, patch_size=16, embed_dim=128, depth=3, num_heads=2, num_frames=2, tubelet_size=1,
+                       clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=(0, 1))
+    s = AdaptationVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=3, encoder_num_heads=2, mlp_ratio=4,
+                                    qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=2, tubelet_size=1,
+                                    clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=[0, 1])
+    sd = fill_state_dict(student_shapes(cfg), 3)
+    s.load_state_dict(sd)
+    for n, p in s.named_parameters():
+        if n.startswith("clip_decoder.1."):
+            p.requires_grad = False                                   # (b) a frozen decoder
+    s = s.to(DEV).train()
+    vid = make_videos(2, 2, 32, 32, seed=5)
+    mask = O.mask_from_importance(make_importance(4, 4, seed=6), 2, 2)
+    tgt = torch.nn.functional.normalize(torch.randn(2, 2, 4, 64, generator=torch.Generator().manual_seed(7)), dim=-1)
+    args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1e-2, opt_eps=1e-8, opt_betas=[0.9, 0.95])
+    opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+    rt = s.runtime()
+    vis, nv = rt.tokens_from_mask(mask.to(DEV))
+    before = {k: v.detach().clone() for k, v in s.state_dict().items()}
+    opt.zero_grad()
+    loss = s.forward_loss(vid.to(DEV), vis, nv, tgt.reshape(-1, 64).to(DEV))
+    gn = NativeScalerWithGradNormCount()(loss, opt, clip_grad=None, parameters=None)
+    # oracle: gradients of the used, trainable parameters only
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = O.student_forward(leaf, vid, mask, cfg, clip_only=True)
+    O.umt_loss(out_ref, tgt).backward()
+    used = [k for k in leaf if leaf[k].grad is not None and not k.startswith("clip_decoder.1.")]
+    assert not any(k.startswith("encoder.blocks.2.") for k in used) and any(k.startswith("encoder.blocks.1.") for k in used)
+    gn_ref = torch.sqrt(sum((leaf[k].grad ** 2).sum() for k in used)).item()
+    assert abs(gn.item() - gn_ref) <= 2e-2 * gn_ref, (gn.item(), gn_ref)
+    after = s.state_dict()
+    for k in before:
+        moved = (after[k] - before[k]).abs().max().item()
+        if k.startswith("encoder.blocks.2.") or k.startswith("clip_decoder.1."):
+            assert moved == 0.0, (k, moved)                          # no gradient -> untouched (no weight decay, no moment update)
+        else:
+            assert moved > 0.0, k
+
+
 def test_drop_path_and_accumulation_tiny(golden_dir):
     """stochastic depth with given keep-vectors vs the oracle; second backward without zero_grad accumulates."""
     z = _load(golden_dir, "student_tiny.npz")

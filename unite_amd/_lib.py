@@ -82,6 +82,7 @@ SIGNATURES = {
     "unite_cast_f32_bf16": (c_i, [c_p, c_p, c_i64, c_p]),
     "unite_grad_norm_workspace": (c_sz, [c_i64]),
     "unite_grad_norm_flat": (c_i, [c_p, c_i64, c_f, c_p, c_p, c_p, c_p]),
+    "unite_grad_norm_flat_masked": (c_i, [c_p, c_i64, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "unite_token_mean_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_token_mean_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_linear_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -53,11 +53,15 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ par
 }
 
 constexpr int GN_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+// chunk_group / skip_group: 1024-element chunks of that optimizer group are left out (parameters without a gradient this step --
+// frozen, or in layers that were not executed: torch's get_grad_norm_ only sees p.grad is not None, utils.py:631-643)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
+                                                            const uint8_t* __restrict__ chunk_group, int skip_group) {
     __shared__ float red[4];
     float s = 0.f;
     const int64_t stride = (int64_t)gridDim.x * 1024;
     for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4; i < n; i += stride) {
+        if (chunk_group && chunk_group[i >> 10] == skip_group) continue;
         if (i + 4 <= n) {
             const f32x4 a = *(const f32x4*)(g + i);
             s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
@@ -116,13 +120,27 @@ extern "C" size_t unite_grad_norm_workspace(int64_t n) {
     return GN_BLOCKS * sizeof(float);
 }
 
+static int grad_norm_impl(const float* grad, int64_t n, const uint8_t* chunk_group, int skip_group, float max_norm, float* norm_out,
+                          float* clip_coef_out, void* workspace, void* stream);
+
 extern "C" int unite_grad_norm_flat(const float* grad, int64_t n, float max_norm, float* norm_out, float* clip_coef_out, void* workspace,
                                     void* stream) {
+    return grad_norm_impl(grad, n, nullptr, -1, max_norm, norm_out, clip_coef_out, workspace, stream);
+}
+
+extern "C" int unite_grad_norm_flat_masked(const float* grad, int64_t n, const uint8_t* chunk_group, int32_t skip_group, float max_norm,
+                                           float* norm_out, float* clip_coef_out, void* workspace, void* stream) {
+    if (!chunk_group || skip_group < 0 || skip_group > 255) return UNITE_EINVAL;
+    return grad_norm_impl(grad, n, chunk_group, skip_group, max_norm, norm_out, clip_coef_out, workspace, stream);
+}
+
+static int grad_norm_impl(const float* grad, int64_t n, const uint8_t* chunk_group, int skip_group, float max_norm, float* norm_out,
+                          float* clip_coef_out, void* workspace, void* stream) {
     if (!grad || !norm_out || !workspace || n <= 0 || (((uintptr_t)grad) & 15)) return UNITE_EINVAL;
     const int64_t want = (n + 1023) / 1024;
     const int nparts = (int)(want < GN_BLOCKS ? want : GN_BLOCKS);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, (float*)workspace);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, (float*)workspace, chunk_group, skip_group);
     UNITE_LAUNCH_CHECK();
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, nparts, max_norm, norm_out, clip_coef_out);
     UNITE_LAUNCH_CHECK();

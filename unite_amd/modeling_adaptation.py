@@ -271,6 +271,7 @@ class _StudentRuntime:
         r.use_slot(slot)
         ws = self.ws
         fp.refresh_if_stale()
+        fp.unused_prefixes = ("clip_decoder.",)      # the encoder-only passes never reach the decoders: no gradient for them (run_stage3.py:475)
         B = videos.shape[0]
         M, D = B * n_vis, self.D
         dp = r.drop_path_scales(B, training)
@@ -321,6 +322,9 @@ class _StudentRuntime:
         M = B * n_vis
         D, C = self.D, self.C
         n_blocks = (max(self.taps) + 1) if clip_only else self.depth       # early break, reference :165-166
+        # blocks above the highest tap are not executed: their parameters get no gradient (p.grad stays None in the reference, so
+        # AdamW and the gradient norm skip them); the optimizer reads this list
+        fp.unused_prefixes = tuple(f"encoder.blocks.{i}." for i in range(n_blocks, self.depth))
         dp = r.drop_path_scales(B, training)
         x0 = r.embed(videos, vis_tokens, M)
         xs = r.blocks_forward(x0, B, n_vis, n_blocks, dp, save=True)

@@ -333,8 +333,13 @@ def grad_norm_workspace(n: int) -> int:
     return int(_lib.load().unite_grad_norm_workspace(n))
 
 
-def grad_norm_flat(grad, norm_out, workspace, max_norm: float = 0.0, clip_coef_out=None):
+def grad_norm_flat(grad, norm_out, workspace, max_norm: float = 0.0, clip_coef_out=None, chunk_group=None, skip_group: int = -1):
+    """chunk_group / skip_group: leave out the 1024-element chunks of that optimizer group (parameters without a gradient this step)"""
     lib = _lib.load()
+    if chunk_group is not None and skip_group >= 0:
+        _lib.check(lib.unite_grad_norm_flat_masked(_ptr(grad), grad.numel(), _ptr(chunk_group), skip_group, max_norm, _ptr(norm_out),
+                                                   _ptr(clip_coef_out), _ptr(workspace), _stream()), "unite_grad_norm_flat_masked")
+        return norm_out
     _lib.check(lib.unite_grad_norm_flat(_ptr(grad), grad.numel(), max_norm, _ptr(norm_out), _ptr(clip_coef_out), _ptr(workspace), _stream()),
                "unite_grad_norm_flat")
     return norm_out

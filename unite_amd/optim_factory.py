@@ -97,14 +97,32 @@ class FusedAdamW(torch.optim.Optimizer):
             if self._ready:
                 self._chunk_group = self._build_chunk_table()
 
+    def _effective_unused(self):
+        """name prefixes without a gradient this step: what the engine declared (set_unused) + what the model's runtime reports
+        (layers its last forward did not execute, e.g. blocks above the highest tap under clip_only)"""
+        return tuple(self._unused) + tuple(getattr(self._flat, "unused_prefixes", ()) or ())
+
+    def no_grad_chunks(self):
+        """(chunk -> group table, id of the group without gradients) for the masked gradient norm; (None, -1) if every parameter has one"""
+        if not self._ready:
+            self._prepare()
+        self._refresh_unused()
+        return (self._chunk_group, self._frozen_group) if self._frozen_group is not None else (None, -1)
+
+    def _refresh_unused(self):
+        eff = self._effective_unused()
+        if eff != getattr(self, "_table_unused", None):
+            self._chunk_group = self._build_chunk_table()
+
     def _build_chunk_table(self):
         fp = self._flat
+        self._table_unused = self._effective_unused()
         name_of = {id(p): n for n, p in zip(fp.names, fp.params)}
         group_of = {}
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 group_of[name_of[id(p)]] = gi
-        missing = [n for n in fp.names if n not in group_of or n.startswith(self._unused or ("\0",))]
+        missing = [n for n in fp.names if n not in group_of or n.startswith(self._table_unused or ("\0",))]
         if missing:
             # parameters outside the optimizer (frozen / filtered / without gradient): a group the kernel skips (lr < 0)
             if len(self.param_groups) >= 64:
@@ -133,6 +151,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self._ready:
             self._prepare()
         fp = self._flat
+        self._refresh_unused()
         self._step += 1
         lrs = [float(g["lr"]) for g in self.param_groups]
         wds = [float(g["weight_decay"]) for g in self.param_groups]

@@ -49,11 +49,11 @@ class NativeScalerWithGradNormCount:
         flat = getattr(optimizer, "_flat", None)
         if flat is None:
             raise RuntimeError("optimizer is not a unite_amd FusedAdamW bound to a flat parameter buffer")
-        norm = self.grad_norm(flat, clip_grad)
+        norm = self.grad_norm(flat, clip_grad, optimizer)
         optimizer.step(grad_scale=self._coef if (clip_grad is not None and clip_grad > 0) else None)
         return norm
 
-    def grad_norm(self, flat, clip_grad=None):
+    def grad_norm(self, flat, clip_grad=None, optimizer=None):
         dev = flat.grad.device
         if self._norm is None:
             # a ring of result slots: the engines keep the returned 0-dim tensors un-read until the next log line (no host sync per
@@ -64,7 +64,10 @@ class NativeScalerWithGradNormCount:
             self._ws = torch.empty(ops.grad_norm_workspace(flat.grad.numel()), dtype=torch.uint8, device=dev)
         self._slot = (self._slot + 1) % self.RING
         out = self._norm[self._slot:self._slot + 1]
-        ops.grad_norm_flat(flat.grad, out, self._ws, max_norm=float(clip_grad or 0.0), clip_coef_out=self._coef)
+        # parameters that have no gradient in this step (frozen, or in layers that were not run) are in a group of their own that the
+        # optimizer skips: they stay out of the norm as well (the reference's norm runs over `p.grad is not None`)
+        table, skip = optimizer.no_grad_chunks() if hasattr(optimizer, "no_grad_chunks") else (None, -1)
+        ops.grad_norm_flat(flat.grad, out, self._ws, max_norm=float(clip_grad or 0.0), clip_coef_out=self._coef, chunk_group=table, skip_group=skip)
         return out[0]                                 # 0-dim device tensor: no host sync here
 
     def state_dict(self):
@@ -328,12 +331,26 @@ def load_state_dict(model, state_dict, prefix='', ignore_missing="relative_posit
     return warn_missing_keys, unexpected_keys        # (the bf16 shadow follows by itself: FlatParams watches tensor versions)
 
 
+def _plain(obj):
+    """numpy scalars / arrays -> Python numbers / lists (the lr schedule is a numpy array, so param_groups and args pick up
+    numpy.float64): what is saved must load with the tensor-only loader, which executes nothing from the file"""
+    if isinstance(obj, np.generic):
+        return obj.item()
+    if isinstance(obj, np.ndarray):
+        return obj.tolist()
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    return obj
+
+
 def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None, tag=None):
     """{'model','optimizer','epoch','scaler','args'} in checkpoint-{epoch|tag}.pth on rank 0 (utils.py:689-736)."""
     output_dir = Path(args.output_dir)
     path = output_dir / ('checkpoint-%s.pth' % (tag if tag is not None else str(epoch)))
-    to_save = {'model': model_without_ddp.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch,
-               'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}
+    to_save = {'model': model_without_ddp.state_dict(), 'optimizer': _plain(optimizer.state_dict()), 'epoch': epoch,
+               'scaler': loss_scaler.state_dict(), 'args': _plain(dict(vars(args))) if hasattr(args, "__dict__") else args}
     save_on_master(to_save, path)
     return path
 
