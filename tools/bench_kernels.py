@@ -42,8 +42,21 @@ def gemm_case(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, epi="
     name = f"{name} [{epi}]" if epi else name
     if ta and tb:
         kw["workspace"] = WS
-    t = timeit(lambda: ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw))
     fl = 2.0 * M * N * K
+    if os.environ.get("AB"):
+        # tile kernels (policy 0) against the persistent kernel wherever it supports the problem (policy 2), interleaved in one process
+        from unite_amd import _lib
+        lib = _lib.load()
+        ts = {0: [], 2: []}
+        for rnd in range(3):
+            for pol in (0, 2):
+                lib.unite_gemm_set_policy(pol)
+                ts[pol].append(timeit(lambda: ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw), iters=10, warm=2))
+        lib.unite_gemm_set_policy(-1)
+        t0, t2 = min(ts[0]), min(ts[2])
+        print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} tb={int(tb)}  tile {t0*1e6:8.1f} us {fl/t0/1e12:7.1f} TF/s | persistent {t2*1e6:8.1f} us {fl/t2/1e12:7.1f} TF/s  ({(t2/t0-1)*100:+5.1f} %)", flush=True)
+        return t0
+    t = timeit(lambda: ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw))
     print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} ta={int(ta)} tb={int(tb)}  {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TF/s  {fl/t/2.5e15*100:5.1f}% peak", flush=True)
     return t
 

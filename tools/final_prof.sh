@@ -13,7 +13,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
 cd $R
 STATS=$(find $O/stats -name "*kernel_stats.csv" | head -1)
-python tools/prof_summary.py $STATS 18 60 > $O/${TAG}_bench_kernel_stats.txt
+TRACE=$(find $O/stats -name "*kernel_trace.csv" | head -1)
+python tools/prof_summary.py $TRACE 60 > $O/${TAG}_bench_kernel_stats.txt
 cp $STATS $O/${TAG}_bench_kernel_stats.csv
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/${TAG}_gemm_traffic.json
 python tools/pmc_kernels.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/${TAG}_mfma_counters.csv > $O/${TAG}_mfma_counters.txt

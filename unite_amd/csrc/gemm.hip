@@ -934,16 +934,23 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         if (rc != UNITE_OK) return rc;
     }
     {
-        // The persistent kernel (gemm_pp.hip) takes the shapes it measured faster on than the tile kernels below (MI355X, round 2,
-        // profiles/r02_kernel_microbench.txt): k-contiguous B with an f32 output at K <= 1024 (proj / out_proj / decoder heads: the residual
-        // epilogue hides under the next tile and one launch fills the chip) and the plain bf16 products of the student (qkv).  The rest --
-        // GELU / QuickGELU epilogues, K = 3072, the k-strided B of the input gradients -- is within +-5 % or slower and stays on the tile
-        // kernels.  UNITE_GEMM_PP = 0 never / 1 measured shapes (default) / 2 whenever supported; UNITE_GEMM_PP_MIN_TILES moves the size floor.
+        // The persistent kernel (gemm_pp.hip) takes the shapes it measured faster on than the tile kernels below (MI355X, round 2, both
+        // in one process: profiles/r02_gemm_ab.txt): k-contiguous B with an f32 output (proj / fc2 / out_proj / c_proj / decoder heads:
+        // -5 .. -21 %, the residual epilogue hides under the next tile and whole 128-byte lines move) and the student's plain and GELU
+        // bf16 products (qkv -14 %, fc1 -3 %).  The teacher's 310-MB bf16 outputs (QuickGELU c_fc, qkv: +1 .. +5 %) and the k-strided B of
+        // the input gradients (+10 .. +18 %: transposing fragment reads with rebuilt addresses) stay on the tile kernels.
+        // UNITE_GEMM_PP = 0 never / 1 measured shapes (default) / 2 whenever supported; UNITE_GEMM_PP_MIN_TILES moves the size floor.
         const int pp = g_pp_policy >= 0 ? g_pp_policy : g_pp_env();
         static const int pp_min = getenv("UNITE_GEMM_PP_MIN_TILES") ? atoi(getenv("UNITE_GEMM_PP_MIN_TILES")) : 64;
         static const char* force_k = getenv("UNITE_GEMM_KERNEL");
-        const bool measured = !g.trans_b && ((g.out_f32 && g.K <= 1024) ||
-                                             (!g.out_f32 && g.act == UNITE_ACT_NONE && g.K <= 1024 && (int64_t)g.M * g.N <= (int64_t)32 << 20));
+        // a launch of 257 .. ~1000 tiles gives the 256 persistent workgroups 1-4 tiles each: badly balanced, most of the epilogues unhidden,
+        // and -- unlike tile kernels, whose workgroups retire tile by tile -- nothing from another stream can slip in meanwhile (the
+        // teacher runs three frame ranges on three streams: 396 tiles per launch; measured +0.5 ms per step there).  UNITE_GEMM_PP_BAND=lo,hi
+        static const char* band_s = getenv("UNITE_GEMM_PP_BAND");
+        static const int band_lo = band_s ? atoi(band_s) : 256, band_hi = (band_s && strchr(band_s, ',')) ? atoi(strchr(band_s, ',') + 1) : 1000;
+        const int pp_tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+        const bool measured = !g.trans_b && (pp_tiles <= band_lo || pp_tiles >= band_hi) &&
+                              (g.out_f32 || (g.act != UNITE_ACT_QUICKGELU && (int64_t)g.M * g.N <= (int64_t)32 << 20));
         if (pp && (pp == 2 || measured) && !force_k && ((g.M + 255) / 256) * ((g.N + 127) / 128) >= pp_min && unite_gemm_pp_supported(g)) {
             hipStream_t s = (hipStream_t)stream;
             const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();

@@ -173,6 +173,18 @@ __device__ __forceinline__ void epi_coords(int m0, int n0, int wm, int wn, int l
     gn = F32OUT ? n0 + wn * 64 + pr * 32 + 4 * G : n0 + wn * 64 + (2 * pr + (G & 1)) * 16 + 8 * (G >> 1);
 }
 
+// f32 outputs leave (and residual rows arrive) in WHOLE 128-byte lines: the MFMA's own layout gives a lane 4 columns of n-tile 2 pr and 4 of
+// n-tile 2 pr + 1 in ONE row, i.e. a store instruction would write 16 rows x 64 bytes (half lines: measured at half the HBM rate).  Lanes c
+// and c ^ 8 of a lane row trade one of their two pieces (DPP row rotate by 8), after which lane (G, c) holds, for memory operation A: row
+// (c & 7) of the m-tile, and for operation B: row (c & 7) + 8 -- both at n-tile 2 pr + (c >> 3): 8 lanes x 16 bytes = one full line per row.
+__device__ __forceinline__ void f32_line_coords(int m0, int n0, int wm, int wn, int lane, int i, int pr, int& gmA, int& gn) {
+    asm volatile("" : "+v"(lane));
+    const int G = lane >> 4, c = lane & 15;
+    gmA = m0 + wm * 64 + i * 16 + (c & 7);            // operation B: gmA + 8
+    gn = n0 + wn * 64 + pr * 32 + (c >> 3) * 16 + 4 * G;
+}
+__device__ __forceinline__ uint32_t rot8(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true); }   // row_ror:8
+
 // first column of the 4 consecutive columns lane (G, c) holds of its n-tile j
 template <bool PERM>
 __device__ __forceinline__ int ncol(int n0, int wn, int j, int lane) {
@@ -196,8 +208,11 @@ __device__ __forceinline__ void epi_issue_loads(const PPParams& p, const Descs& 
     epi_coords<F32OUT, E>(m0, n0, wm, wn, lane, gm, gn);
     const bool okm = gm < g.M;
     if (F32OUT) {
-        asm_load_b128(e.r0, (okm && gn < g.N) ? (uint32_t)(gm * g.ldr + gn) * 4u : OOB_OFFSET, d.res);
-        asm_load_b128(e.r1, (okm && gn + 16 < g.N) ? (uint32_t)(gm * g.ldr + gn + 16) * 4u : OOB_OFFSET, d.res);
+        int gmA, gl;
+        f32_line_coords(m0, n0, wm, wn, lane, E >> 1, E & 1, gmA, gl);
+        const bool okn = gl < g.N;
+        asm_load_b128(e.r0, (okn && gmA < g.M) ? (uint32_t)(gmA * g.ldr + gl) * 4u : OOB_OFFSET, d.res);           // line layout, operation A
+        asm_load_b128(e.r1, (okn && gmA + 8 < g.M) ? (uint32_t)((gmA + 8) * g.ldr + gl) * 4u : OOB_OFFSET, d.res);   // operation B
         asm_load_b32(e.sc, okm ? __umulhi((uint32_t)gm, p.rps_magic) * 4u : OOB_OFFSET, d.scale);
     } else {
         asm_load_b128(e.r0, (okm && gn < g.N) ? (uint32_t)(gm * g.ld_aux_in + gn) * 2u : OOB_OFFSET, d.aux_in);      // 8 bf16 pre-activations
@@ -220,12 +235,22 @@ __device__ __forceinline__ EpiOut epi_math(const PPParams& p, EpiRegs& e, const 
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] *= e.sc;
         }
+        // to the line layout: a lane keeps the piece of its own half (c < 8: n-tile 2 pr, c >= 8: n-tile 2 pr + 1) and trades the other one
+        // with lane c ^ 8; operation A then carries row c & 7, operation B row (c & 7) + 8
+        const bool hi = (__lane_id() & 8) != 0;
+        float a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float got = __uint_as_float(rot8(__float_as_uint(hi ? v[r] : v[4 + r])));
+            a[r] = hi ? got : v[r];
+            b[r] = hi ? v[4 + r] : got;
+        }
         if (g.residual) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] += e.r0[r]; v[4 + r] += e.r1[r]; }
+            for (int r = 0; r < 4; ++r) { a[r] += e.r0[r]; b[r] += e.r1[r]; }
         }
-        out.o0 = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        out.o1 = (u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+        out.o0 = (u32x4){__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
+        out.o1 = (u32x4){__float_as_uint(b[0]), __float_as_uint(b[1]), __float_as_uint(b[2]), __float_as_uint(b[3])};
     } else {
         // v_permlane16_swap: the odd lane rows of the first operand trade places with the even lane rows of the second.  Before: lane row
         // G holds columns 4 G .. + 3 of both tiles.  After: (v[r] | v[4 + r]) are 8 consecutive columns of ONE tile (epi_coords).
@@ -264,8 +289,10 @@ __device__ __forceinline__ void epi_store(const PPParams& p, const Descs& d, con
     epi_coords<F32OUT, E>(m0, n0, wm, wn, lane, gm, gn);
     const bool okm = gm < g.M;
     if (F32OUT) {
-        const uint32_t o0 = (okm && gn < g.N) ? (uint32_t)(gm * g.ldc + gn) * 4u : OOB_OFFSET;
-        const uint32_t o1 = (okm && gn + 16 < g.N) ? (uint32_t)(gm * g.ldc + gn + 16) * 4u : OOB_OFFSET;
+        int gmA, gl;
+        f32_line_coords(m0, n0, wm, wn, lane, E >> 1, E & 1, gmA, gl);
+        const uint32_t o0 = (gl < g.N && gmA < g.M) ? (uint32_t)(gmA * g.ldc + gl) * 4u : OOB_OFFSET;
+        const uint32_t o1 = (gl < g.N && gmA + 8 < g.M) ? (uint32_t)((gmA + 8) * g.ldc + gl) * 4u : OOB_OFFSET;
         __builtin_amdgcn_raw_buffer_store_b128(out.o0, d.out, o0, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(out.o1, d.out, o1, 0, 0);
     } else {
