@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one HIP stream for the whole run (no side-stream weight gradients, no multi-stream "
                                                           "teacher): per-kernel durations are then undisturbed, as in the roofline pass")
+    ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step in a HIP graph and replay it (single rank; measured SLOWER than "
+                                                        "eager launches on ROCm 7.0: DESIGN.md section 5); 0 (default): eager launches")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of the N>1 flow on one GPU)")
     a = ap.parse_args()
 
@@ -146,15 +148,26 @@ def main():
         state.overlap_targets = False
     it = [0]
 
+    use_graph = a.graph == 1
+    graphed = None
+    if use_graph:
+        if world > 1:
+            raise SystemExit("--graph 1 is single-rank (the bucket all-reduces go through torch.distributed: eager)")
+        from unite_amd.graph_step import GraphedStage1Step
+        graphed = GraphedStage1Step(model, teacher, opt, scaler, tuple(videos.shape), 0.8, clip_grad=None, state=state)
+
     def step():
         i = it[0]
         for g in opt.param_groups:
             g["lr"] = lr_sched[min(i, len(lr_sched) - 1)] * g["lr_scale"]
+        it[0] += 1
+        if graphed is not None and not graph_off[0]:
+            return graphed(videos)
         loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
         opt.zero_grad()
         gn = scaler(loss, opt, clip_grad=None, parameters=None, reducer=reducer)
-        it[0] += 1
         return loss, gn
+    graph_off = [False]
 
     def fence():
         if world > 1:
@@ -204,6 +217,7 @@ def main():
 
     roof = None
     if not a.no_roofline:
+        graph_off[0] = True             # the per-launch events of the roofline pass need eager launches
         set_concurrency(False)          # kernel durations of the roofline pass must not include time shared with other kernels
     if not a.no_roofline and rank == 0:
         lib = _lib.load()
@@ -248,13 +262,15 @@ def main():
 
     if not a.no_roofline:
         set_concurrency(not a.serial)
+        graph_off[0] = False
     if rank == 0:
         out = {"metric": "stage-1 train clips/sec (ViT-B/16, 8fx224^2)", "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "stage1 UMT pretrain, ViT-B/16 student + CLIP-B/16 teacher, synthetic 8fx224^2 clips, "
                                       f"B={B}/GPU, mask_ratio=0.8, bf16 MFMA + fp32 accumulate/master (BASELINE configs[1])",
-                          "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05"},
+                          "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05",
+                          "launch": "hip_graph" if graphed is not None else "eager"},
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)}
         if roof is not None:

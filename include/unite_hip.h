@@ -227,6 +227,11 @@ int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_
  * generator keyed by (seed, element) -- the same two-valued distribution {0, 1/keep} as the reference's
  * x.div(keep) * floor(keep + rand).  keep: device f32 [layers]; out: device f32 [layers*per_layer]. */
 int unite_drop_path_scales(const float* keep, uint64_t seed, float* out, int32_t layers, int32_t per_layer, void* stream);
+/* Graph-replayable forms: the seed is read from device memory at run time (`seed_dev`, one uint64 the host rewrites between
+ * replays), so a captured launch draws fresh masks / keep-vectors every time it is replayed. */
+int unite_mask_sample_dev(const float* weights, const uint64_t* seed_dev, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                          int32_t BT, int32_t N, int32_t n_vis, void* stream);
+int unite_drop_path_scales_dev(const float* keep, const uint64_t* seed_dev, float* out, int32_t layers, int32_t per_layer, void* stream);
 /* Same outputs from an explicit permutation (int64 [BT,N], the reference's `importance`). */
 int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                int32_t BT, int32_t N, int32_t n_vis, void* stream);
@@ -284,6 +289,12 @@ int unite_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp
                      const float* lr, const float* weight_decay, int32_t n_groups,
                      float beta1, float beta2, float eps, int32_t step,
                      const float* grad_scale_dev, const int32_t* found_inf_dev, void* stream);
+/* Graph-replayable form: learning rates, weight decays and the two bias-correction factors are read from device memory at run
+ * time -- hp_dev: f32 [130] = lr[64] | weight_decay[64] | 1 / (1 - beta1^t) | 1 / sqrt(1 - beta2^t), rewritten by the host between
+ * replays (run_stage1.py:326-338 writes the schedule into param_groups every step). */
+int unite_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                         const uint8_t* chunk_group, int64_t n_elems, const float* hp_dev, float beta1, float beta2, float eps,
+                         const float* grad_scale_dev, const int32_t* found_inf_dev, void* stream);
 
 /* y[m,:] = bf16(row_scale[m / rows_per_scale] * x[m,:])  (f32 [M,D] -> bf16; the GEMM-operand copy of a gradient that did not
  * come out of a LayerNorm backward, e.g. the token-mean gradient of stage 2). */

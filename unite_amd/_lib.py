@@ -71,6 +71,9 @@ SIGNATURES = {
     "unite_l2_normalize_rows": (c_i, [c_p, c_i, c_i, c_p]),
     "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_drop_path_scales": (c_i, [c_p, c_u64, c_p, c_i, c_i, c_p]),
+    "unite_mask_sample_dev": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "unite_drop_path_scales_dev": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "unite_adamw_flat_dev": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_f, c_f, c_f, c_p, c_p, c_p]),
     "unite_mask_from_importance": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_mask_to_tokens": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_greedy_masks": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -102,7 +102,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 // one workgroup (256 threads) per frame row; N <= 256.  keys in LDS; rank by counting; ascending compaction by scan.
-__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const int64_t* __restrict__ importance,
+__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                          const int64_t* __restrict__ importance,
                                                           const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask,
                                                           int32_t* __restrict__ vis_tokens, int32_t* __restrict__ vis_rows_cls, int BT, int N,
                                                           int n_vis) {
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
         float k = INFINITY;
         if (j < N) {
             const float w = weights[(size_t)bt * N + j];
-            const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)bt << 20) + (uint64_t)j + 1));
+            const uint64_t sd = seed_dev ? *seed_dev : seed;      // device-resident seed: the launch can be replayed from a HIP graph
+            const uint64_t h = splitmix64(sd ^ splitmix64(((uint64_t)bt << 20) + (uint64_t)j + 1));
             const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
             k = (w > 0.f) ? -__logf(u) / w : INFINITY;                             // exponential race
         }
@@ -156,12 +158,13 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
 // timm drop_path as the blocks use it (reference modeling_finetune.py:42-53): per residual branch and sample the multiplier
 // floor(keep + U[0,1)) / keep.  out[l * per_layer + i] for layer l with keep probability keep[l]; counter-based uniforms
 // (splitmix64 of seed and element index), so no generator state lives on the device and nothing syncs with the host.
-__global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __restrict__ keep, uint64_t seed, float* __restrict__ out,
-                                                               int per_layer, int total) {
+__global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __restrict__ keep, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                               float* __restrict__ out, int per_layer, int total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const float k = keep[i / per_layer];
-    const uint64_t h = splitmix64(seed ^ splitmix64(0xD809A7ull + (uint64_t)i));
+    const uint64_t sd = seed_dev ? *seed_dev : seed;
+    const uint64_t h = splitmix64(sd ^ splitmix64(0xD809A7ull + (uint64_t)i));
     const float u = (float)(h >> 40) * (1.0f / 16777216.0f);      // [0,1)
     out[i] = floorf(k + u) / k;
 }
@@ -620,7 +623,16 @@ extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t 
 extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                  int32_t BT, int32_t N, int32_t n_vis, void* stream) {
     if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const int64_t*)nullptr,
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const uint64_t*)nullptr,
+                       (const int64_t*)nullptr, (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_mask_sample_dev(const float* weights, const uint64_t* seed_dev, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
+                                     int32_t BT, int32_t N, int32_t n_vis, void* stream) {
+    if (!weights || !seed_dev || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, 0ull, seed_dev, (const int64_t*)nullptr,
                        (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -629,7 +641,16 @@ extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* m
 extern "C" int unite_drop_path_scales(const float* keep, uint64_t seed, float* out, int32_t layers, int32_t per_layer, void* stream) {
     if (!keep || !out || layers <= 0 || per_layer <= 0) return UNITE_EINVAL;
     const int total = layers * per_layer;
-    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, seed, out, per_layer, total);
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, seed, (const uint64_t*)nullptr, out,
+                       per_layer, total);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_drop_path_scales_dev(const float* keep, const uint64_t* seed_dev, float* out, int32_t layers, int32_t per_layer, void* stream) {
+    if (!keep || !seed_dev || !out || layers <= 0 || per_layer <= 0) return UNITE_EINVAL;
+    const int total = layers * per_layer;
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, keep, 0ull, seed_dev, out, per_layer, total);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
@@ -637,7 +658,7 @@ extern "C" int unite_drop_path_scales(const float* keep, uint64_t seed, float* o
 extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                           int32_t BT, int32_t N, int32_t n_vis, void* stream) {
     if (!importance || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, importance,
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr, importance,
                        (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -646,7 +667,7 @@ extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* ma
 extern "C" int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls, int32_t BT, int32_t N,
                                     int32_t n_vis, void* stream) {
     if (!mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull,
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr,
                        (const int64_t*)nullptr, mask, (uint8_t*)nullptr, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;

@@ -1,6 +1,7 @@
 // Fused AdamW + global gradient norm over ONE flat fp32 parameter buffer (HBM-bound streaming kernels).
 // Algorithmic traffic of the AdamW step: read p, g, m, v (16 B) + write p, m, v (12 B) + bf16 shadow (2 B) = 30 B / element.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -14,13 +15,17 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ par
                                                          float* __restrict__ v, uint16_t* __restrict__ pbf, const uint8_t* __restrict__ chunk_group,
                                                          int64_t n, GroupTable tab, float beta1, float beta2, float eps, float inv_bc1,
                                                          float inv_sqrt_bc2, const float* __restrict__ grad_scale_dev,
-                                                         const int32_t* __restrict__ found_inf_dev) {
+                                                         const int32_t* __restrict__ found_inf_dev, const float* __restrict__ hp_dev) {
     if (found_inf_dev && *found_inf_dev) return;
+    if (hp_dev) {      // device-resident hyper-parameters (lr[64], wd[64], 1 / bc1, 1 / sqrt(bc2)): the launch is replayable from a HIP graph
+        inv_bc1 = hp_dev[2 * MAX_GROUPS];
+        inv_sqrt_bc2 = hp_dev[2 * MAX_GROUPS + 1];
+    }
     const float gs = grad_scale_dev ? *grad_scale_dev : 1.0f;
     const int64_t nchunks = (n + 1023) >> 10;
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int gidx = chunk_group ? chunk_group[chunk] : 0;
-        const float lr = tab.lr[gidx], wd = tab.wd[gidx];
+        const float lr = hp_dev ? hp_dev[gidx] : tab.lr[gidx], wd = hp_dev ? hp_dev[MAX_GROUPS + gidx] : tab.wd[gidx];
         if (lr < 0.f) continue;              // group without gradients this step: torch.optim.AdamW's `if p.grad is None: continue`
         const float decay = 1.0f - lr * wd, step = lr * inv_bc1;
         const int64_t i = (chunk << 10) + threadIdx.x * 4;
@@ -110,7 +115,23 @@ extern "C" int unite_adamw_flat(float* param, const float* grad, float* exp_avg,
     const unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
                        (uint16_t*)param_bf16, chunk_group, n_elems, tab, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
-                       grad_scale_dev, found_inf_dev);
+                       grad_scale_dev, found_inf_dev, (const float*)nullptr);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                                    const uint8_t* chunk_group, int64_t n_elems, const float* hp_dev, float beta1, float beta2, float eps,
+                                    const float* grad_scale_dev, const int32_t* found_inf_dev, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hp_dev || n_elems <= 0) return UNITE_EINVAL;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) || (((uintptr_t)param_bf16) & 7))
+        return UNITE_EINVAL;
+    GroupTable tab;
+    memset(&tab, 0, sizeof(tab));
+    const int64_t nchunks = (n_elems + 1023) >> 10;
+    const unsigned grid = (unsigned)(nchunks < 256 * 16 ? nchunks : 256 * 16);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       (uint16_t*)param_bf16, chunk_group, n_elems, tab, beta1, beta2, eps, 1.0f, 1.0f, grad_scale_dev, found_inf_dev, hp_dev);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

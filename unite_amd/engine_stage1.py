@@ -33,6 +33,7 @@ class StepState:
         self.vis = None
         self.rows = None
         self.seed = 0
+        self.step_params = None          # graph_step.StepParams: the mask sampler then reads its seed from device memory
         self.overlap_targets = os.environ.get("UNITE_OVERLAP_TARGETS", "1") != "0"
 
 
@@ -65,8 +66,11 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
     if importance is not None:                                   # explicit permutation (parity tests)
         ops.mask_from_importance(importance, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows)
     elif mask_type == 'attention':
-        state.seed += 1
-        ops.mask_sample(attn, state.seed, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows)   # :382-387
+        if state.step_params is not None:      # captured step: the host advanced and published the seed before the launch
+            ops.mask_sample(attn, 0, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows, seed_dev=state.step_params.seed_mask_dev)
+        else:
+            state.seed += 1
+            ops.mask_sample(attn, state.seed, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows)   # :382-387
     else:
         m8 = bool_masked_pos.to(dev).flatten(1).to(torch.uint8).contiguous().view(-1)
         state.mask = m8

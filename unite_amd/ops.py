@@ -263,19 +263,29 @@ def l2_normalize_rows(x):
     return x
 
 
-def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int, vis_rows_cls=None):
+def mask_sample(weights, seed: int, mask, vis_tokens, n_vis: int, vis_rows_cls=None, seed_dev=None):
+    """seed_dev: optional device int64 [1] holding the seed (graph-replayable form); `seed` is ignored then"""
     lib = _lib.load()
     BT, N = weights.shape
+    if seed_dev is not None:
+        _lib.check(lib.unite_mask_sample_dev(_ptr(weights), _ptr(seed_dev), _ptr(mask), _ptr(vis_tokens), _ptr(vis_rows_cls), BT, N, n_vis,
+                                             _stream()), "unite_mask_sample_dev")
+        return
     _lib.check(lib.unite_mask_sample(_ptr(weights), seed & 0xFFFFFFFFFFFFFFFF, _ptr(mask), _ptr(vis_tokens), _ptr(vis_rows_cls),
                                      BT, N, n_vis, _stream()), "unite_mask_sample")
 
 
-def drop_path_scales(keep, seed: int, out):
-    """out (layers, ...) f32 <- floor(keep[l] + u) / keep[l] (timm drop_path multipliers); keep: device f32 [layers]."""
+def drop_path_scales(keep, seed: int, out, seed_dev=None):
+    """out (layers, ...) f32 <- floor(keep[l] + u) / keep[l] (timm drop_path multipliers); keep: device f32 [layers].
+    seed_dev: optional device int64 [1] holding the seed (graph-replayable form)."""
     lib = _lib.load()
     _req(keep, F32, "keep"); _req(out, F32, "out")
     layers = keep.numel()
     assert out.is_contiguous() and out.numel() % layers == 0
+    if seed_dev is not None:
+        _lib.check(lib.unite_drop_path_scales_dev(_ptr(keep), _ptr(seed_dev), _ptr(out), layers, out.numel() // layers, _stream()),
+                   "unite_drop_path_scales_dev")
+        return out
     _lib.check(lib.unite_drop_path_scales(_ptr(keep), seed & 0xFFFFFFFFFFFFFFFF, _ptr(out), layers, out.numel() // layers, _stream()),
                "unite_drop_path_scales")
     return out
@@ -321,6 +331,17 @@ def adamw_flat(param, grad, exp_avg, exp_avg_sq, param_bf16, chunk_group, lrs: S
     _lib.check(lib.unite_adamw_flat(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(param_bf16), _ptr(chunk_group),
                                     param.numel(), lr_arr, wd_arr, n, beta1, beta2, eps, step, _ptr(grad_scale), _ptr(found_inf),
                                     _stream()), "unite_adamw_flat")
+
+
+def adamw_flat_dev(param, grad, exp_avg, exp_avg_sq, param_bf16, chunk_group, hp_dev, beta1: float, beta2: float, eps: float,
+                   grad_scale=None, found_inf=None):
+    """AdamW with lr / weight decay / bias corrections read from device memory (hp_dev f32 [130]): graph-replayable"""
+    lib = _lib.load()
+    _req(hp_dev, F32, "hp_dev")
+    assert hp_dev.numel() >= 130
+    _lib.check(lib.unite_adamw_flat_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(param_bf16), _ptr(chunk_group),
+                                        param.numel(), _ptr(hp_dev), beta1, beta2, eps, _ptr(grad_scale), _ptr(found_inf), _stream()),
+               "unite_adamw_flat_dev")
 
 
 def cast_f32_bf16(src, dst):

@@ -8,6 +8,8 @@ of ``unite_adamw_flat`` over the model's flat parameter buffer, which also refre
 """
 from __future__ import annotations
 
+import math
+
 from typing import Dict, List, Optional
 
 import torch
@@ -87,6 +89,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._ready = False
         self._unused = ()
+        self._step_params = None
 
     def set_unused(self, prefixes):
         """parameters (by name prefix) that receive no gradient in this training stage: torch.optim.AdamW skips p.grad is None
@@ -146,19 +149,44 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(fp.param)
         self._ready = True
 
-    @torch.no_grad()
-    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
-        if not self._ready:
-            self._prepare()
-        fp = self._flat
-        self._refresh_unused()
-        self._step += 1
+    def use_step_params(self, params):
+        """graph_step.StepParams: lr / wd / bias corrections are then read from device memory by the kernel (a captured step() launch stays
+        valid while the schedule moves); the caller stages them with stage_hparams() before every launch"""
+        self._step_params = params
+
+    def _hparams(self):
         lrs = [float(g["lr"]) for g in self.param_groups]
         wds = [float(g["weight_decay"]) for g in self.param_groups]
         if self._frozen_group is not None:
             lrs.append(-1.0)
             wds.append(0.0)
+        return lrs, wds
+
+    def stage_hparams(self, params):
+        """advance the step count and put this step's group table and Adam bias corrections into `params` (host side)"""
+        if not self._ready:
+            self._prepare()
+        self._refresh_unused()
+        self._step += 1
+        params.lrs, params.wds = self._hparams()
+        # exactly what unite_adamw_flat computes on the host: the betas rounded to f32 first, the powers in double
+        import numpy as np
+        b1, b2 = (float(np.float32(b)) for b in self.param_groups[0]["betas"])
+        params.inv_bc = (1.0 / (1.0 - b1 ** self._step), 1.0 / math.sqrt(1.0 - b2 ** self._step))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
+        if not self._ready:
+            self._prepare()
+        fp = self._flat
         b1, b2 = self.param_groups[0]["betas"]
+        if self._step_params is not None:
+            ops.adamw_flat_dev(fp.param, fp.grad, self.exp_avg, self.exp_avg_sq, fp.shadow, self._chunk_group, self._step_params.hp,
+                               float(b1), float(b2), float(self.param_groups[0]["eps"]), grad_scale=grad_scale, found_inf=found_inf)
+            return
+        self._refresh_unused()
+        self._step += 1
+        lrs, wds = self._hparams()
         ops.adamw_flat(fp.param, fp.grad, self.exp_avg, self.exp_avg_sq, fp.shadow, self._chunk_group, lrs, wds,
                        float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step, grad_scale=grad_scale, found_inf=found_inf)
 

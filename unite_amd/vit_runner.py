@@ -73,6 +73,13 @@ class ViTRunner:
         self.wgrad_stream = os.environ.get("UNITE_WGRAD_STREAM", "1") != "0"
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
+        self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
+
+    def next_drop_path_seed(self) -> int:
+        if getattr(self, "_dp_seed", None) is None:
+            self._dp_seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF      # follows torch.manual_seed(seed + rank)
+        self._dp_seed = (self._dp_seed + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+        return self._dp_seed
 
     def _side_stream(self):
         if self._side is None:
@@ -132,10 +139,10 @@ class ViTRunner:
             return None
         if getattr(self, "_keep", None) is None:        # uploaded once: a host -> device copy here would block the host every step
             self._keep = (1.0 - torch.tensor(self.dp_rates, dtype=F32)).to(self.fp.device)
-            self._dp_seed = (torch.initial_seed() * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF      # follows torch.manual_seed(seed + rank)
-        self._dp_seed = (self._dp_seed + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
         out = self.ws.get("dp.scales", (self.depth, 2, B), F32)
-        return ops.drop_path_scales(self._keep, self._dp_seed, out)
+        if self.step_params is not None:       # captured step: the host advanced and published the seed before the launch
+            return ops.drop_path_scales(self._keep, 0, out, seed_dev=self.step_params.seed_dp_dev)
+        return ops.drop_path_scales(self._keep, self.next_drop_path_seed(), out)
 
     # ------------------------------------------------------------------ forward
     def embed(self, videos: torch.Tensor, tokens: Optional[torch.Tensor], M: int) -> torch.Tensor:
