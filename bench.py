@@ -95,6 +95,9 @@ def main():
                                                           "teacher): per-kernel durations are then undisturbed, as in the roofline pass")
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step in a HIP graph and replay it (single rank; measured SLOWER than "
                                                         "eager launches on ROCm 7.0: DESIGN.md section 5); 0 (default): eager launches")
+    ap.add_argument("--ahead", type=int, default=int(os.environ.get("UNITE_TEACHER_AHEAD", "1")),
+                    help="1: the frozen teacher runs one batch ahead of the student on its own stream (engine_stage1.TeacherAhead, what "
+                         "train_one_epoch does by default); 0: teacher and student of a step strictly one after the other")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of the N>1 flow on one GPU)")
     a = ap.parse_args()
 
@@ -118,7 +121,7 @@ def main():
     import unite_amd
     from unite_amd import _lib
     from unite_amd.ddp import DistributedDataParallel
-    from unite_amd.engine_stage1 import StepState, stage1_step
+    from unite_amd.engine_stage1 import StepState, TeacherAhead, stage1_step, student_phase
     from unite_amd.optim_factory import create_optimizer
     from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
     from types import SimpleNamespace
@@ -156,6 +159,9 @@ def main():
         from unite_amd.graph_step import GraphedStage1Step
         graphed = GraphedStage1Step(model, teacher, opt, scaler, tuple(videos.shape), 0.8, clip_grad=None, state=state)
 
+    ahead = TeacherAhead(teacher, state, dev, 0.8, 'attention') if (a.ahead == 1 and not a.serial and not use_graph) else None
+    touts = []
+
     def step():
         i = it[0]
         for g in opt.param_groups:
@@ -163,7 +169,16 @@ def main():
         it[0] += 1
         if graphed is not None and not graph_off[0]:
             return graphed(videos)
-        loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
+        if ahead is not None and not graph_off[0]:
+            # every step enqueues ONE teacher phase (for the step after it) and ONE student step (on the outputs of the teacher phase
+            # enqueued a step earlier): K timed steps = K teacher forwards + K student steps, as in train_one_epoch
+            if not touts:
+                touts.append(ahead.launch(videos))
+            cur = touts.pop()
+            touts.append(ahead.launch(videos))
+            loss = student_phase(model, videos, cur, B, 'mixed')
+        else:
+            loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
         opt.zero_grad()
         gn = scaler(loss, opt, clip_grad=None, parameters=None, reducer=reducer)
         return loss, gn
@@ -174,14 +189,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        loss, gn = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, gn = step()
-    t_enq = time.perf_counter() - t0          # the host has enqueued every launch of the timed steps (nothing synchronises inside a step)
-    fence()
+    sprio = os.environ.get("UNITE_STUDENT_PRIO")
+    sctx = torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(sprio))) if sprio is not None else contextlib.nullcontext()
+    with sctx:
+        for _ in range(a.warmup):
+            loss, gn = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss, gn = step()
+        t_enq = time.perf_counter() - t0          # the host has enqueued every launch of the timed steps (nothing synchronises inside a step)
+        fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -270,7 +288,8 @@ def main():
                "config": {"workload": "stage1 UMT pretrain, ViT-B/16 student + CLIP-B/16 teacher, synthetic 8fx224^2 clips, "
                                       f"B={B}/GPU, mask_ratio=0.8, bf16 MFMA + fp32 accumulate/master (BASELINE configs[1])",
                           "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05",
-                          "launch": "hip_graph" if graphed is not None else "eager"},
+                          "launch": "hip_graph" if graphed is not None else "eager",
+                          "schedule": "teacher one batch ahead of the student (own stream)" if ahead is not None else "teacher then student"},
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)}
         if roof is not None:

@@ -88,6 +88,8 @@ int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
  * supports the problem, -1 back to the UNITE_GEMM_PP environment variable.  Results are the same either way (f32 accumulation
  * in K order inside a K-tile; integer-valued products are bit-exact on both). */
 int unite_gemm_set_policy(int32_t persistent);
+/* the value last set (-1 if the environment variable decides): lets a caller change the policy for a group of launches and put it back */
+int unite_gemm_get_policy(void);
 
 /* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
  * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117

@@ -238,7 +238,10 @@ def test_stage3_cfg4_batch_split_property():
     l_all, g_all = run(0, B)
     l_a, g_a = run(0, B // 2)
     l_b, g_b = run(B // 2, B)
-    assert abs(l_all - 0.5 * (l_a + l_b)) <= 1e-4 * abs(l_all)
+    # 3e-4: the GEMM planner picks kernels by tile count, i.e. differently for 4 and for 2 clips; the persistent kernel adds the bias before the
+    # products and the tile kernels after them, so bf16-rounded activations differ in their last bit here and there (measured 1.1e-4 on the
+    # cross-entropy; with one kernel family pinned the difference is < 1e-4)
+    assert abs(l_all - 0.5 * (l_a + l_b)) <= 3e-4 * abs(l_all)
     assert rel_l2(g_all, 0.5 * (g_a + g_b)) <= 2e-3
     (lo, hi), = rt.fp.layer_ranges(["clip_decoder."])
     assert g_all[lo:hi].abs().max().item() == 0

@@ -118,9 +118,10 @@ class VisionTransformer(nn.Module):
         return self.runtime().cls_features(videos)
 
     @torch.no_grad()
-    def visible_targets(self, vis_rows_cls, n_rows):
-        """ln_post + proj + L2-norm of the taps at the listed rows only -> f32 [K*n_rows, C] (run_stage1.py:389-397)."""
-        return self.runtime().targets(vis_rows_cls, n_rows)
+    def visible_targets(self, vis_rows_cls, n_rows, slot=0):
+        """ln_post + proj + L2-norm of the taps at the listed rows only -> f32 [K*n_rows, C] (run_stage1.py:389-397).
+        ``slot`` picks the output buffer (the engine's teacher-ahead mode keeps two batches' targets alive)."""
+        return self.runtime().targets(vis_rows_cls, n_rows, slot)
 
 
 class _TeacherRuntime:
@@ -314,10 +315,10 @@ class _TeacherRuntime:
         ops.gemm(aa, w["w_pr"], xo, bias=w["b_pr"], residual=x1)
         return xo
 
-    def targets(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
+    def targets(self, rows: torch.Tensor, n_rows: int, slot: int = 0) -> torch.Tensor:
         ws, D, C = self.ws, self.D, self.C
         K = len(self.taps)
-        out = ws.get("targets", (K * n_rows, C), F32)
+        out = ws.get("targets" if slot == 0 else f"targets.{slot}", (K * n_rows, C), F32)
         xn = ws.get("tail.xn", (n_rows, D), BF16)
         for k in range(K):
             if self._last is not None and k == K - 1:          # the last block's tap exists for these rows only

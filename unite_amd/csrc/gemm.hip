@@ -922,6 +922,7 @@ extern "C" int unite_gemm_set_policy(int32_t persistent) {
     g_pp_policy = persistent;
     return UNITE_OK;
 }
+extern "C" int unite_gemm_get_policy(void) { return g_pp_policy; }
 int unite_gemm_pp_supported(const unite_gemm_args& g);
 int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_bytes, hipStream_t s);
 

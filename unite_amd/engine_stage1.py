@@ -29,9 +29,10 @@ class StepState:
     """Device buffers of the stage-1 step that persist across iterations."""
 
     def __init__(self):
-        self.mask = None
+        self.mask = None                 # the buffers of the slot used last (tests read them)
         self.vis = None
         self.rows = None
+        self.slots = {}                  # slot -> (mask, vis, rows): two slots when the teacher runs one batch ahead
         self.seed = 0
         self.step_params = None          # graph_step.StepParams: the mask sampler then reads its seed from device memory
         self.overlap_targets = os.environ.get("UNITE_OVERLAP_TARGETS", "1") != "0"
@@ -48,49 +49,69 @@ def teacher_input(teacher_model, videos, clip_input_resolution):
     return ops.resize_bicubic(videos.contiguous(), out)
 
 
-def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state: StepState,
-                clip_input_resolution=224, importance=None):
-    """teacher -> mask -> targets -> student loss (device tensors only).  Returns the 0-dim loss tensor (with grad_fn)."""
-    student = getattr(model, "module", model)
-    rt = student.runtime()
+class TeacherOut:
+    """What the student needs from the teacher for one batch: the visible-token list and the targets of those tokens."""
+    __slots__ = ("mask", "vis", "rows", "n_vis", "targets", "ready", "foreign")   # ready: event behind `targets`; foreign: ... and behind vis too
+
+
+def teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos, state: StepState, clip_input_resolution=224,
+                  importance=None, slot=0, inline_targets=False) -> TeacherOut:
+    """teacher forward -> attention-guided mask -> targets of the visible tokens (run_stage1.py:360-397).  Everything is enqueued on
+    the current stream, except that with ``state.overlap_targets`` (and not ``inline_targets``) the target tail goes to the teacher's
+    side stream and ``ready`` is the event the consumer waits for."""
     dev = videos.device
     B, C, T, H, W = videos.shape
     attn = teacher_model.forward_attention(teacher_input(teacher_model, videos, clip_input_resolution))     # (B*T, N) f32
     BT, N = attn.shape
     n_vis_frame = N - int(N * mask_ratio)                        # :380
     n_vis = n_vis_frame * (BT // B)
-    if state.mask is None or state.mask.numel() != BT * N:
-        state.mask = torch.empty(BT * N, dtype=torch.uint8, device=dev)
-        state.vis = torch.empty(BT * n_vis_frame, dtype=torch.int32, device=dev)
-        state.rows = torch.empty(BT * n_vis_frame, dtype=torch.int32, device=dev)
+    bufs = state.slots.get(slot)
+    if bufs is None or bufs[0].numel() != BT * N or bufs[1].numel() != BT * n_vis_frame:
+        bufs = (torch.empty(BT * N, dtype=torch.uint8, device=dev), torch.empty(BT * n_vis_frame, dtype=torch.int32, device=dev),
+                torch.empty(BT * n_vis_frame, dtype=torch.int32, device=dev))
+        state.slots[slot] = bufs
+    mask, vis, rows = bufs
     if importance is not None:                                   # explicit permutation (parity tests)
-        ops.mask_from_importance(importance, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows)
+        ops.mask_from_importance(importance, mask, vis, n_vis_frame, vis_rows_cls=rows)
     elif mask_type == 'attention':
         if state.step_params is not None:      # captured step: the host advanced and published the seed before the launch
-            ops.mask_sample(attn, 0, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows, seed_dev=state.step_params.seed_mask_dev)
+            ops.mask_sample(attn, 0, mask, vis, n_vis_frame, vis_rows_cls=rows, seed_dev=state.step_params.seed_mask_dev)
         else:
             state.seed += 1
-            ops.mask_sample(attn, state.seed, state.mask, state.vis, n_vis_frame, vis_rows_cls=state.rows)   # :382-387
+            ops.mask_sample(attn, state.seed, mask, vis, n_vis_frame, vis_rows_cls=rows)   # :382-387
     else:
-        m8 = bool_masked_pos.to(dev).flatten(1).to(torch.uint8).contiguous().view(-1)
-        state.mask = m8
-        ops.mask_to_tokens(m8, state.vis, n_vis_frame, BT, N, vis_rows_cls=state.rows)
+        mask = bool_masked_pos.to(dev).flatten(1).to(torch.uint8).contiguous().view(-1)
+        ops.mask_to_tokens(mask, vis, n_vis_frame, BT, N, vis_rows_cls=rows)
+    state.mask, state.vis, state.rows = mask, vis, rows
+    out = TeacherOut()
+    out.mask, out.vis, out.rows, out.n_vis, out.ready, out.foreign = mask, vis, rows, n_vis, None, False
     M = B * n_vis
     # The teacher's tail (last block on the visible rows, ln_post, proj, L2) is only needed by the loss: it runs on the teacher's
     # side stream under the student's encoder forward.
     trt = getattr(teacher_model, "module", teacher_model).runtime()
-    ready = None
-    if state.overlap_targets and videos.is_cuda:
+    if state.overlap_targets and videos.is_cuda and not inline_targets:
         main, side = torch.cuda.current_stream(), trt._side_stream()
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            targets = teacher_model.visible_targets(state.rows, M)       # f32 [K*M, C], rows in (k, b, token) order
-            ready = torch.cuda.Event()
-            ready.record(side)
+            out.targets = teacher_model.visible_targets(rows, M, slot=slot)      # f32 [K*M, C], rows in (k, b, token) order
+            out.ready = torch.cuda.Event()
+            out.ready.record(side)
     else:
-        targets = teacher_model.visible_targets(state.rows, M)
+        out.targets = teacher_model.visible_targets(rows, M, slot=slot)
+    return out
+
+
+def student_phase(model, videos, tout: TeacherOut, n_source, clip_loss_data):
+    """student forward on the visible tokens + decoders + UMT loss (run_stage1.py:410-438).  Returns the 0-dim loss (with grad_fn)."""
+    B, C, T, H, W = videos.shape
+    n_vis, targets, ready = tout.n_vis, tout.targets, tout.ready
+    if tout.foreign and ready is not None:         # the whole teacher phase ran on another stream: the token list is needed first
+        torch.cuda.current_stream().wait_event(ready)
+        ready = None
+    M = B * n_vis
+    N = tout.mask.numel() // (B * T)
     # which clips take part in the loss (:418-427).  Samples are independent in the student, so restricting the loss to a
     # slice of the batch equals running the student on that slice only.
     if clip_loss_data == 'mixed':
@@ -110,9 +131,85 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
         K = targets.shape[0] // M
         targets = targets.view(K, B, n_vis, -1)[:, lo:hi].contiguous().view(K * (hi - lo) * n_vis, -1)
         videos_l = videos[lo:hi].contiguous()
-        vis_l = (state.vis.view(B, n_vis)[lo:hi] - lo * T * N).contiguous().view(-1)
+        vis_l = (tout.vis.view(B, n_vis)[lo:hi] - lo * T * N).contiguous().view(-1)
         return model.forward_loss(videos_l, vis_l, n_vis, targets)
-    return model.forward_loss(videos, state.vis, n_vis, targets, targets_ready=ready)
+    return model.forward_loss(videos, tout.vis, n_vis, targets, targets_ready=ready)
+
+
+def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state: StepState,
+                clip_input_resolution=224, importance=None):
+    """teacher -> mask -> targets -> student loss (device tensors only).  Returns the 0-dim loss tensor (with grad_fn)."""
+    tout = teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos, state, clip_input_resolution, importance)
+    return student_phase(model, videos, tout, n_source, clip_loss_data)
+
+
+class TeacherAhead:
+    """The frozen teacher one batch ahead of the student: ``launch(videos)`` enqueues the whole teacher phase of a batch on a stream of
+    its own and returns its TeacherOut; the caller then trains the student on the PREVIOUS batch, whose teacher phase was launched an
+    iteration earlier.  Nothing in the teacher depends on the student (frozen, no_grad: run_stage1.py:371), so the arithmetic of every
+    step is that of stage1_step; what changes is that the student's many short, partially filled launches (and, on N GPUs, its gradient
+    all-reduces) share the GPU with the teacher's long GEMMs.  Outputs alternate between two slots.
+
+    Measured on MI355X (B = 32): 23.7 -> 22.0 ms per step.  Beside a concurrent student the teacher is best left on ONE
+    stream (its three frame-range streams: +0.4 ms) and on the tile GEMM kernels (the persistent kernel keeps every CU for a whole launch,
+    so nothing of the student slips in between its tiles: +0.2 ms); UNITE_TEACHER_AHEAD_STREAMS / UNITE_TEACHER_PP change that."""
+
+    def __init__(self, teacher_model, state: StepState, device, mask_ratio, mask_type, clip_input_resolution=224):
+        self.teacher, self.state = teacher_model, state
+        self.mask_ratio, self.mask_type, self.res = mask_ratio, mask_type, clip_input_resolution
+        self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("UNITE_TEACHER_AHEAD_PRIO", "0")))
+        self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
+        self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))          # -1: whatever the process-wide policy is
+        self.n = 0
+
+    def launch(self, videos, bool_masked_pos=None, importance=None) -> TeacherOut:
+        from . import _lib
+        slot = self.n & 1
+        self.n += 1
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)                    # the batch is on the device, and the student step that last read this slot has been enqueued
+        self.stream.wait_event(ev)
+        trt = getattr(self.teacher, "module", self.teacher).runtime()
+        keep = trt.n_streams
+        trt.n_streams = self.n_streams
+        lib = _lib.load()
+        policy_before = lib.unite_gemm_get_policy()
+        try:
+            with torch.cuda.stream(self.stream):
+                if self.gemm_policy >= 0:
+                    lib.unite_gemm_set_policy(self.gemm_policy)      # read by the launches as they are enqueued, i.e. by this phase only
+                out = teacher_phase(self.teacher, videos, self.mask_ratio, self.mask_type, bool_masked_pos, self.state, self.res,
+                                    importance, slot=slot, inline_targets=True)
+                out.ready = torch.cuda.Event()
+                out.ready.record(self.stream)
+                out.foreign = True
+        finally:
+            trt.n_streams = keep
+            if self.gemm_policy >= 0:
+                lib.unite_gemm_set_policy(policy_before)
+        return out
+
+
+class _Ahead:
+    """iterates (batch, TeacherOut) with the teacher phase of the following batch already enqueued"""
+
+    def __init__(self, loader, prepare, ahead: TeacherAhead, mask_type):
+        self.loader, self.prepare, self.ahead, self.mask_type = loader, prepare, ahead, mask_type
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        prev = None
+        for batch in self.loader:
+            cur = self.prepare(batch)
+            tout = self.ahead.launch(cur[0], cur[1] if self.mask_type != 'attention' else None)
+            if prev is not None:
+                yield prev
+            prev = (cur, tout)
+        if prev is not None:
+            yield prev
 
 
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_train_target: Optional[Iterable],
@@ -158,15 +255,9 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                 log_writer.update(grad_norm=gv, head="opt")
                 log_writer.set_step()
 
-    for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
-        it = start_steps + step
-        if lr_schedule_values is not None or wd_schedule_values is not None:
-            for param_group in optimizer.param_groups:
-                if lr_schedule_values is not None:
-                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
-                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
-                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
-
+    def prepare(batch):
+        """source (+ target) clips of one iteration on the device (:344-358) -> (videos, bool_masked_pos, n_source)"""
+        nonlocal target_iter
         videos, bool_masked_pos, labels_s = batch
         B_s = videos.shape[0]
         if target_iter is not None:
@@ -178,10 +269,36 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
             videos = torch.cat([videos, videos_t], dim=0)
             if mask_type != 'attention':
                 bool_masked_pos = torch.cat([bool_masked_pos, bool_masked_pos_t], dim=0)
-        videos = videos.to(device, non_blocking=True)
+        return videos.to(device, non_blocking=True), bool_masked_pos, B_s
 
-        loss = stage1_step(model, teacher_model, videos, B_s, mask_ratio, mask_type, bool_masked_pos,
-                           getattr(args, "clip_loss_data", "mixed"), state, clip_input_resolution)
+    # teacher one batch ahead (default on a GPU; UNITE_TEACHER_AHEAD=0 or args.teacher_ahead=False restores the strictly sequential step)
+    ahead_on = getattr(args, "teacher_ahead", None)
+    if ahead_on is None:
+        ahead_on = os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0"
+    ahead_on = bool(ahead_on) and torch.device(device).type == "cuda" and state.step_params is None
+    clip_loss_data = getattr(args, "clip_loss_data", "mixed")
+    if ahead_on:
+        ahead = TeacherAhead(teacher_model, state, device, mask_ratio, mask_type, clip_input_resolution)
+        source = _Ahead(data_loader, prepare, ahead, mask_type)
+    else:
+        source = data_loader
+
+    for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
+        it = start_steps + step
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
+                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
+
+        if ahead_on:
+            (videos, bool_masked_pos, B_s), tout = item
+            loss = student_phase(model, videos, tout, B_s, clip_loss_data)
+        else:
+            videos, bool_masked_pos, B_s = prepare(item)
+            loss = stage1_step(model, teacher_model, videos, B_s, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state,
+                               clip_input_resolution)
         optimizer.zero_grad()
         grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
         pending.append((loss, grad_norm))

@@ -15,7 +15,14 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """the current HIP stream of the current device as an integer handle (torch.cuda.current_stream() costs ~8 us of Python per call,
+    600 calls per step; the raw accessor ~0.3 us)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
