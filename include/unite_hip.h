@@ -91,6 +91,15 @@ int unite_gemm_set_policy(int32_t persistent);
 /* the value last set (-1 if the environment variable decides): lets a caller change the policy for a group of launches and put it back */
 int unite_gemm_get_policy(void);
 
+/* How much of the GPU the caller's launches share with independent work on other streams (stage 1: the frozen teacher runs one batch
+ * ahead of the student, run_stage1.py:360-397 vs :410-456).  The planner picks tile size and split-K by
+ *     (1 - w) * latency of the launch alone on the GPU  +  w * CU time it occupies (workgroups x time each / resident slots + reduction pass)
+ * w = 0 (default): the launch is alone, a partially filled last round is wasted, split-K and small tiles pay; w -> 1: whatever it leaves
+ * idle is used by the other stream, so fewer, larger workgroups win (256 x 256 tiles, fewer split-K slices).  0 <= w <= 1; results do
+ * not depend on it beyond the f32 summation order of split-K.  UNITE_GEMM_PLAN_WORK in the environment pins the value. */
+int unite_gemm_set_sharing(float work_weight);
+float unite_gemm_get_sharing(void);
+
 /* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
  * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117
  * under autograd) fill the chip together instead of each needing split-K slabs.  Results are identical to `count`

@@ -809,6 +809,10 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // kind 1: 128^2 tile, 512 resident (2 / CU), (c, e) = (1.006, 4.4);  kind 2: 256^2, 256 resident, (1.51, 9.8);
 // kind 3: 128 x 256, 512 resident, (1.58, 9.0).  S > 1 only for plain f32 outputs with a workspace (weight gradients).
 struct Plan { int kind, splitk; double cost; };
+// 0 .. 1: weight of the CU time a launch takes against its latency when the planner picks tile size and split-K (unite_gemm_set_sharing);
+// UNITE_GEMM_PLAN_WORK pins it for experiments
+double g_plan_work = getenv("UNITE_GEMM_PLAN_WORK") ? atof(getenv("UNITE_GEMM_PLAN_WORK")) : 0.0;
+
 inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only = false) {
     const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
     const int slots[4] = {0, 512, 256, 512};
@@ -824,6 +828,13 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
             const double rounds = (double)((tiles[kind] * S + slots[kind] - 1) / slots[kind]);
             double cost = rounds * (kts * cc[kind] + ee[kind]);
             if (S > 1) cost += 3.0 + (double)S * M * N * 8.0 / 5.0e6;      // slab write + read at ~5 TB/s, one more launch
+            // g_plan_work > 0: the launch shares the GPU with an independent stream (teacher one batch ahead), so what it costs the step is
+            // less its own latency than the CU time it takes: workgroups x time each, over the resident slots, + the reduction pass
+            if (g_plan_work > 0.0) {
+                double work = (double)tiles[kind] * S * (kts * cc[kind] + ee[kind]) / slots[kind];
+                if (S > 1) work += (double)S * M * N * 8.0 / 5.0e6;
+                cost = (1.0 - g_plan_work) * cost + g_plan_work * work;
+            }
             if (cost < best.cost - 1e-9) best = {kind, S, cost};
         }
     }
@@ -923,6 +934,13 @@ extern "C" int unite_gemm_set_policy(int32_t persistent) {
     return UNITE_OK;
 }
 extern "C" int unite_gemm_get_policy(void) { return g_pp_policy; }
+extern "C" int unite_gemm_set_sharing(float work_weight) {
+    if (!(work_weight >= 0.f && work_weight <= 1.f)) return UNITE_EINVAL;
+    static const bool pinned = getenv("UNITE_GEMM_PLAN_WORK") != nullptr;
+    if (!pinned) g_plan_work = (double)work_weight;
+    return UNITE_OK;
+}
+extern "C" float unite_gemm_get_sharing(void) { return (float)g_plan_work; }
 int unite_gemm_pp_supported(const unite_gemm_args& g);
 int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_bytes, hipStream_t s);
 

@@ -51,7 +51,7 @@ def teacher_input(teacher_model, videos, clip_input_resolution):
 
 class TeacherOut:
     """What the student needs from the teacher for one batch: the visible-token list and the targets of those tokens."""
-    __slots__ = ("mask", "vis", "rows", "n_vis", "targets", "ready", "foreign")   # ready: event behind `targets`; foreign: ... and behind vis too
+    __slots__ = ("mask", "vis", "rows", "n_vis", "targets", "ready", "foreign", "videos")   # ready: event behind `targets`; foreign: ... and behind vis too
 
 
 def teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos, state: StepState, clip_input_resolution=224,
@@ -84,7 +84,7 @@ def teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos,
         ops.mask_to_tokens(mask, vis, n_vis_frame, BT, N, vis_rows_cls=rows)
     state.mask, state.vis, state.rows = mask, vis, rows
     out = TeacherOut()
-    out.mask, out.vis, out.rows, out.n_vis, out.ready, out.foreign = mask, vis, rows, n_vis, None, False
+    out.mask, out.vis, out.rows, out.n_vis, out.ready, out.foreign, out.videos = mask, vis, rows, n_vis, None, False, videos
     M = B * n_vis
     # The teacher's tail (last block on the visible rows, ln_post, proj, L2) is only needed by the loss: it runs on the teacher's
     # side stream under the student's encoder forward.
@@ -110,6 +110,8 @@ def student_phase(model, videos, tout: TeacherOut, n_source, clip_loss_data):
     if tout.foreign and ready is not None:         # the whole teacher phase ran on another stream: the token list is needed first
         torch.cuda.current_stream().wait_event(ready)
         ready = None
+        if videos.is_cuda:
+            videos.record_stream(torch.cuda.current_stream())       # it may have been allocated on the teacher's stream (host batch)
     M = B * n_vis
     N = tout.mask.numel() // (B * T)
     # which clips take part in the loss (:418-427).  Samples are independent in the student, so restricting the loss to a
@@ -150,7 +152,8 @@ class TeacherAhead:
     step is that of stage1_step; what changes is that the student's many short, partially filled launches (and, on N GPUs, its gradient
     all-reduces) share the GPU with the teacher's long GEMMs.  Outputs alternate between two slots.
 
-    Measured on MI355X (B = 32): 23.7 -> 22.0 ms per step.  Beside a concurrent student the teacher is best left on ONE
+    Measured on MI355X (B = 32): 23.7 -> 21.6 ms per step, 20.4 with the GEMM planner told that launches share the
+    GPU (unite_gemm_set_sharing: larger tiles, fewer split-K slices).  Beside a concurrent student the teacher is best left on ONE
     stream (its three frame-range streams: +0.4 ms) and on the tile GEMM kernels (the persistent kernel keeps every CU for a whole launch,
     so nothing of the student slips in between its tiles: +0.2 ms); UNITE_TEACHER_AHEAD_STREAMS / UNITE_TEACHER_PP change that."""
 
@@ -160,16 +163,37 @@ class TeacherAhead:
         self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("UNITE_TEACHER_AHEAD_PRIO", "0")))
         self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
         self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))          # -1: whatever the process-wide policy is
+        self.n_slots = max(2, int(os.environ.get("UNITE_TEACHER_AHEAD_SLOTS", "3")))
         self.n = 0
+        # both phases now share the GPU: the GEMM planner weighs the CU time of a launch against its latency (include/unite_hip.h)
+        from . import _lib
+        lib = _lib.load()
+        self._sharing_before = lib.unite_gemm_get_sharing()
+        lib.unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
+        self._marks = []                   # events on the student's stream, one per launch
+
+    def close(self):
+        """back to the planner setting found at construction (the launches already enqueued keep theirs)"""
+        from . import _lib
+        _lib.load().unite_gemm_set_sharing(self._sharing_before)
 
     def launch(self, videos, bool_masked_pos=None, importance=None) -> TeacherOut:
+        """``videos`` may still be on the host: the copy then goes on the teacher's stream too (TeacherOut.videos is the device tensor)."""
         from . import _lib
-        slot = self.n & 1
+        slot = self.n % self.n_slots
         self.n += 1
         main = torch.cuda.current_stream()
+        # Slot reuse: this launch overwrites the outputs read by the student step n_slots launches back.  That step was enqueued before the
+        # launch n_slots - 2 calls ago, so the mark recorded THEN is late enough -- with three slots the teacher may start on batch i+1
+        # while the student is still on batch i-1, and neither stream waits for the other at every step (with two slots: mark of this call).
         ev = torch.cuda.Event()
-        ev.record(main)                    # the batch is on the device, and the student step that last read this slot has been enqueued
-        self.stream.wait_event(ev)
+        ev.record(main)
+        self._marks.append(ev)
+        if len(self._marks) > self.n_slots - 1:
+            self._marks.pop(0)
+        self.stream.wait_event(self._marks[0])
+        if not videos.is_cuda:
+            self.stream.wait_event(ev)     # pinned host buffers are filled by the loader before this call; nothing else to order
         trt = getattr(self.teacher, "module", self.teacher).runtime()
         keep = trt.n_streams
         trt.n_streams = self.n_streams
@@ -179,11 +203,14 @@ class TeacherAhead:
             with torch.cuda.stream(self.stream):
                 if self.gemm_policy >= 0:
                     lib.unite_gemm_set_policy(self.gemm_policy)      # read by the launches as they are enqueued, i.e. by this phase only
+                if not videos.is_cuda:
+                    videos = videos.to(self.stream.device, non_blocking=True)
                 out = teacher_phase(self.teacher, videos, self.mask_ratio, self.mask_type, bool_masked_pos, self.state, self.res,
                                     importance, slot=slot, inline_targets=True)
                 out.ready = torch.cuda.Event()
                 out.ready.record(self.stream)
                 out.foreign = True
+                out.videos = videos
         finally:
             trt.n_streams = keep
             if self.gemm_policy >= 0:
@@ -255,8 +282,14 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                 log_writer.update(grad_norm=gv, head="opt")
                 log_writer.set_step()
 
+    # teacher one batch ahead (default on a GPU; UNITE_TEACHER_AHEAD=0 or args.teacher_ahead=False restores the strictly sequential step)
+    ahead_on = getattr(args, "teacher_ahead", None)
+    if ahead_on is None:
+        ahead_on = os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0"
+    ahead_on = bool(ahead_on) and torch.device(device).type == "cuda" and state.step_params is None
+
     def prepare(batch):
-        """source (+ target) clips of one iteration on the device (:344-358) -> (videos, bool_masked_pos, n_source)"""
+        """source (+ target) clips of one iteration (:344-358) -> (videos, bool_masked_pos, n_source)"""
         nonlocal target_iter
         videos, bool_masked_pos, labels_s = batch
         B_s = videos.shape[0]
@@ -269,13 +302,10 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
             videos = torch.cat([videos, videos_t], dim=0)
             if mask_type != 'attention':
                 bool_masked_pos = torch.cat([bool_masked_pos, bool_masked_pos_t], dim=0)
-        return videos.to(device, non_blocking=True), bool_masked_pos, B_s
+        if not ahead_on:
+            videos = videos.to(device, non_blocking=True)
+        return videos, bool_masked_pos, B_s          # teacher-ahead: TeacherAhead.launch copies the batch on the teacher's stream
 
-    # teacher one batch ahead (default on a GPU; UNITE_TEACHER_AHEAD=0 or args.teacher_ahead=False restores the strictly sequential step)
-    ahead_on = getattr(args, "teacher_ahead", None)
-    if ahead_on is None:
-        ahead_on = os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0"
-    ahead_on = bool(ahead_on) and torch.device(device).type == "cuda" and state.step_params is None
     clip_loss_data = getattr(args, "clip_loss_data", "mixed")
     if ahead_on:
         ahead = TeacherAhead(teacher_model, state, device, mask_ratio, mask_type, clip_input_resolution)
@@ -293,7 +323,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                     param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
 
         if ahead_on:
-            (videos, bool_masked_pos, B_s), tout = item
+            (_, bool_masked_pos, B_s), tout = item
+            videos = tout.videos
             loss = student_phase(model, videos, tout, B_s, clip_loss_data)
         else:
             videos, bool_masked_pos, B_s = prepare(item)
@@ -315,6 +346,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
         metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)
+    if ahead_on:
+        ahead.close()
     flush()
     metric_logger.synchronize_between_processes()
     print(f"[{time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())}] Averaged stats:", metric_logger)

@@ -71,6 +71,8 @@ class ViTRunner:
         self._slot = ""
         self.scale = 64 ** -0.5                 # head_dim ** -0.5 (modeling_finetune.py:86)
         self.wgrad_stream = os.environ.get("UNITE_WGRAD_STREAM", "1") != "0"
+        # how many streams the four weight-gradient GEMMs of a block are spread over (1: one after the other)
+        self.wgrad_streams = min(4, max(1, int(os.environ.get("UNITE_WGRAD_STREAMS", "1"))))
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
         self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
@@ -81,10 +83,12 @@ class ViTRunner:
         self._dp_seed = (self._dp_seed + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
         return self._dp_seed
 
-    def _side_stream(self):
+    def _side_stream(self, k: int = 0):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.fp.device)
-        return self._side
+            self._side = []
+        while len(self._side) <= k:
+            self._side.append(torch.cuda.Stream(device=self.fp.device))
+        return self._side[k]
 
     def use_slot(self, slot: str) -> None:
         """Switch the set of saved activations / scratch buffers (stage 3 runs several forward passes of different
@@ -213,31 +217,41 @@ class ViTRunner:
         acc = fp.accumulate
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
-        gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
+        nside = self.wgrad_streams if (dx.is_cuda and self.wgrad_stream) else 1
+        gws_k = [ws.bytes_("gemm.ws" if k == 0 else f"gemm.ws.{k}", SPLITK_WS_BYTES) for k in range(nside)]      # split-K slabs: one set per stream
+        csws_k = [csws if k == 0 else ws.bytes_(f"cs.ws.{k}", ops.colsum_workspace(M, max(Hd, 3 * D))) for k in range(nside)]
         gcws = ws.bytes_("gemm.cs.ws", ops.gemm_colsum_workspace(M, Hd))
         # Weight-gradient GEMMs and bias column sums are off the critical path (nothing in the backward chain reads them): they
         # run on a side HIP stream behind events, concurrently with the next dgrad GEMM / LayerNorm backward / attention backward
         # on the main stream, which leave MFMA or HBM headroom.  Their operands (dz, dx1b, dqkv, the incoming dxb) live in
         # buffers alternated by block parity, so the main stream only has to wait for the side work of two blocks ago.
         side = self._side_stream() if dx.is_cuda and self.wgrad_stream else None
+        sides = [self._side_stream(k) for k in range(nside)] if side is not None else []
         main = torch.cuda.current_stream() if side is not None else None
-        done_ev = {}
+        done_ev = {}                                # block -> events, one per side stream that worked for it
 
-        def on_side(ev_fn):
-            """run ev_fn() on the side stream after everything issued so far on the main stream"""
+        def on_side(ev_fn, k=0, blk=None):
+            """run ev_fn(k) on side stream k (modulo the number in use) after everything issued so far on the main stream; with ``blk``
+            the stream's position afterwards is one of the events that mark block blk's weight gradients as written"""
             if side is None:
-                ev_fn()
+                ev_fn(0)
                 return
+            k %= nside
             ev = torch.cuda.Event()
             ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ev_fn()
+            sides[k].wait_event(ev)
+            with torch.cuda.stream(sides[k]):
+                ev_fn(k)
+                if blk is not None:
+                    e2 = torch.cuda.Event()
+                    e2.record(sides[k])
+                    done_ev.setdefault(blk, {})[k] = e2      # a later call on the same stream supersedes the earlier event
 
         def retire(j):
             """the main stream may overwrite the parity buffers block j's side-stream work read"""
             if side is not None and j in done_ev:
-                main.wait_event(done_ev.pop(j))
+                for e in done_ev.pop(j).values():
+                    main.wait_event(e)
 
         def report(j):
             """every gradient of block j is written: the side stream's part at done_ev[j], the main stream's part (LayerNorm
@@ -250,7 +264,7 @@ class ViTRunner:
                 return
             ev = torch.cuda.Event()
             ev.record(main)
-            layer_done(j, (ev, done_ev[j]))
+            layer_done(j, (ev, *done_ev[j].values()))
 
         for i in reversed(range(n_blocks)):
             w, s = self._blk[i], self.saved[i]
@@ -268,12 +282,15 @@ class ViTRunner:
             # (one grouped launch of the block's four weight gradients -- ops.gemm_grouped -- is 12 % faster in isolation at 10 240
             # tokens but slower in the step: its 252 MB of operands have left the Infinity Cache by the end of the block)
 
-            def mlp_wgrads(dxb=dxb, dz=dz, w=w, s=s):
-                ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-                ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
+            def fc2_wgrad(k, dxb=dxb, w=w, s=s):
+                ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+
+            def fc1_wgrad(k, dz=dz, w=w, s=s):
+                ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
                 if not self.fused_colsum:
-                    ops.colsum(dz, w["g:mlp.fc1.bias"], csws, accumulate=acc)
-            on_side(mlp_wgrads)
+                    ops.colsum(dz, w["g:mlp.fc1.bias"], csws_k[k], accumulate=acc)
+            on_side(fc2_wgrad, 0, i)
+            on_side(fc1_wgrad, 1, i)
             dh2 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dz, w["mlp.fc1.weight"], dh2, trans_b=True)
             dx1 = ws.get("bw.dx1", (M, D), F32)
@@ -285,21 +302,18 @@ class ViTRunner:
             # ---- attention branch
             do = ws.get("bw.do", (M, D), BF16)
             ops.gemm(dx1b, w["attn.proj.weight"], do, trans_b=True)
-            on_side(lambda dx1b=dx1b, w=w, s=s: ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc,
-                                                        workspace=gws))
+            on_side(lambda k, dx1b=dx1b, w=w, s=s: ops.gemm(dx1b, s["o"], w["g:attn.proj.weight"], trans_a=True, trans_b=True, accumulate=acc,
+                                                           workspace=gws_k[k]), 2, i)
             dqkv = ws.get(f"bw.dqkv{par}", (M, 3 * D), BF16)
             delta = ws.get("bw.delta", (B, H, N), F32)
             ops.attn_bwd(s["qkv"], s["o"], do, s["lse"], delta, dqkv, B, N, H, self.scale)
             dh1 = ws.get("bw.dh", (M, D), BF16)
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
 
-            def qkv_wgrads(dqkv=dqkv, w=w, s=s, i=i):
-                ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)
-                ops.colsum(dqkv, w["g:qkv_bias"], csws, accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
-                if side is not None:
-                    done_ev[i] = torch.cuda.Event()
-                    done_ev[i].record(side)
-            on_side(qkv_wgrads)
+            def qkv_wgrads(k, dqkv=dqkv, w=w, s=s):
+                ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+                ops.colsum(dqkv, w["g:qkv_bias"], csws_k[k], accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
+            on_side(qkv_wgrads, 3, i)
             # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
             # branch's drop-path factor) or the patch-embed weight gradient (unscaled)
             dx0 = ws.get(f"bw.dx{i & 1}", (M, D), F32)
