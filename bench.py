@@ -160,6 +160,9 @@ def main():
         graphed = GraphedStage1Step(model, teacher, opt, scaler, tuple(videos.shape), 0.8, clip_grad=None, state=state)
 
     ahead = TeacherAhead(teacher, state, dev, 0.8, 'attention') if (a.ahead == 1 and not a.serial and not use_graph) else None
+    if a.ahead == 1 and a.serial:
+        # --serial profiles the kernels of the default step one at a time: keep the planner setting that step runs with
+        _lib.load().unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
     touts = []
 
     def step():
@@ -217,12 +220,19 @@ def main():
         teacher.runtime().two_streams = on
         state.overlap_targets = on
 
-    # the step by phase (as tools/phase_time.py): the frozen teacher alone in a steady-state loop with the same streams as the timed region;
-    # student = step - teacher (student forward / backward / AdamW; the teacher's target tail runs under the student's forward)
+    # the step by phase (as tools/phase_time.py): the frozen teacher ALONE on the GPU in a steady-state loop, configured as in the timed region;
+    # student = step - teacher (student forward / backward / AdamW).  With the teacher one batch ahead the two phases overlap in the timed
+    # region, so this difference is what the student adds to a step, not the time its kernels would take alone.
     teacher_ms = None
     if not a.no_roofline:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_t = min(a.steps, 20)
+        trt, lib_ = teacher.runtime(), _lib.load()
+        keep_streams, keep_policy = trt.n_streams, lib_.unite_gemm_get_policy()
+        if ahead is not None:           # the teacher as the timed region runs it: one stream, tile GEMM kernels
+            trt.n_streams = ahead.n_streams
+            if ahead.gemm_policy >= 0:
+                lib_.unite_gemm_set_policy(ahead.gemm_policy)
         for _ in range(3):
             teacher.forward_attention(videos)
         torch.cuda.synchronize()
@@ -232,6 +242,8 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         teacher_ms = ev0.elapsed_time(ev1) / n_t
+        trt.n_streams = keep_streams
+        lib_.unite_gemm_set_policy(keep_policy)
 
     roof = None
     if not a.no_roofline:
@@ -250,6 +262,23 @@ def main():
         lib.unite_prof_enable(0, 0)
         print(f"[bench] profiled pass: {cnt.value} MFMA-kernel launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # the same pass with every launch planned for a GPU of its own (sharing weight 0): what the kernels reach when they are both
+        # configured and measured stand-alone
+        ach_alone = None
+        share = lib.unite_gemm_get_sharing()
+        if share > 0:
+            lib.unite_gemm_set_sharing(0.0)
+            step()
+            lib.unite_prof_enable(1, 400 * n_prof)
+            torch.cuda.synchronize()
+            for _ in range(n_prof):
+                step()
+            torch.cuda.synchronize()
+            ms2, cnt2, fl2 = C.c_double(), C.c_int64(), C.c_double()
+            lib.unite_prof_summary(C.byref(ms2), C.byref(cnt2), C.byref(fl2))
+            lib.unite_prof_enable(0, 0)
+            lib.unite_gemm_set_sharing(share)
+            ach_alone = fl2.value / (ms2.value * 1e-3) / 1e12 if ms2.value > 0 else None
         # HBM bytes per MFMA-kernel launch: NOT measured by this run (PMC counters need rocprofv3: tools/final_prof.sh collects the
         # FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` and tools/pmc_traffic.py reduces them); quoted with its source, or null
         traffic, traffic_source = None, None
@@ -262,6 +291,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM kernels: gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues) + teacher_qkv_attn_kernel (projection + attention FLOPs)", "achieved": round(ach, 1),
                 "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                 "traffic_source": traffic_source,
+                "frac_planned_alone": None if ach_alone is None else round(ach_alone * 1e12 / PEAK_BF16, 4),
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
@@ -270,17 +300,36 @@ def main():
                 "student_step_frac": round(B * GF_STUDENT / ((ms_step - teacher_ms) * 1e-3) / PEAK_BF16, 4),
                 "teacher_frac": round(B * GF_TEACHER / (teacher_ms * 1e-3) / PEAK_BF16, 4),
                 "note": "HIP events on the launch stream around every launch of these kernels in a second pass of the same steps, run on ONE stream "
-                        "(the timed region overlaps weight-gradient GEMMs and the teacher's frame ranges on side streams, which would "
-                        "charge each launch for time it shares with other kernels); same numbers as `bench.py --serial` under rocprofv3"}
+                        "(the timed region overlaps the teacher of the next batch, the student and its weight-gradient GEMMs on separate streams, "
+                        "which would charge each launch for time it shares with other kernels); same kernels and planner setting as the timed "
+                        "region, same numbers as `bench.py --serial` under rocprofv3.  The planner sizes launches for a SHARED GPU "
+                        "(unite_gemm_set_sharing 0.8: larger tiles, fewer split-K slices), so these stand-alone durations are longer "
+                        "than with UNITE_GEMM_SHARING=0 (frac_planned_alone: the same pass planned and measured stand-alone) while the step is shorter: step_frac is the number that counts the whole step"}
     elif world > 1:
-        # keep ranks in lock-step with rank 0's profiled pass
-        for _ in range(min(a.steps, 5)):
+        # keep ranks in lock-step with rank 0's profiled passes (every step all-reduces)
+        n_prof = min(a.steps, 5)
+        for _ in range(n_prof + ((1 + n_prof) if _lib.load().unite_gemm_get_sharing() > 0 else 0)):
             step()
         torch.cuda.synchronize()
 
     if not a.no_roofline:
         set_concurrency(not a.serial)
         graph_off[0] = False
+
+    # what one step costs the HOST: the same step at B = 2, where the GPU work (~3 ms) is shorter than the enqueue, so wall time per step is
+    # host time per step (t_enq of the timed region mostly measures back-pressure: the launch queue is full while the GPU is ~20 ms behind)
+    host_ms = None
+    if world == 1 and not a.no_roofline:
+        v2, st2 = videos[:2].contiguous(), StepState()
+        for k in range(13):
+            if k == 3:
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+            l2 = stage1_step(model, teacher, v2, 2, 0.8, 'attention', None, 'mixed', st2)
+            opt.zero_grad()
+            scaler(l2, opt, clip_grad=None, parameters=None, reducer=reducer)
+        torch.cuda.synchronize()
+        host_ms = (time.perf_counter() - th) / 10 * 1e3
     if rank == 0:
         out = {"metric": "stage-1 train clips/sec (ViT-B/16, 8fx224^2)", "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -291,7 +340,8 @@ def main():
                           "launch": "hip_graph" if graphed is not None else "eager",
                           "schedule": "teacher one batch ahead of the student (own stream)" if ahead is not None else "teacher then student"},
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
-               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3)}
+               "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
+               "host_ms_per_step_unblocked": None if host_ms is None else round(host_ms, 3)}
         if roof is not None:
             out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1:

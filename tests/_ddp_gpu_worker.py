@@ -24,7 +24,7 @@ def main():
     from tests.shapes import TINY_S, TINY_T, TINY_V, student_shapes, teacher_shapes, vit_shapes
     from unite_amd.clip import VisionTransformer as Teacher
     from unite_amd.ddp import DistributedDataParallel
-    from unite_amd.engine_stage1 import StepState, stage1_step
+    from unite_amd.engine_stage1 import StepState, TeacherAhead, stage1_step, student_phase
     from unite_amd.modeling_adaptation import AdaptationVisionTransformer
     from unite_amd.modeling_finetune import VisionTransformer as Vit
     from unite_amd.optim_factory import create_optimizer
@@ -65,6 +65,21 @@ def main():
     res["s1.launched"] = model.reducer.launched
     res["s1.grad"] = rt.fp.grad.clone().cpu()
     res["s1.loss"] = loss.item()
+    # the same two steps with the teacher one batch ahead on its own stream (what train_one_epoch / bench.py run by default): the reducer's
+    # buckets and the teacher's stream are independent of each other, the reduced gradient is the same
+    ahead = TeacherAhead(t, StepState(), dev, 0.5, 'attention', clip_input_resolution=32)
+    mine, imp_mine = vid[lo:hi].contiguous(), imp[lo * 2:hi * 2].contiguous()
+    nxt = ahead.launch(mine, importance=imp_mine)
+    for it in range(2):
+        cur, nxt = nxt, ahead.launch(mine, importance=imp_mine)
+        rt.fp.accumulate = False
+        loss = student_phase(model, mine, cur, per, 'mixed')
+        loss.backward()
+        model.reducer.finish()
+        torch.cuda.synchronize()
+    ahead.close()
+    res["s1.ahead_grad"] = rt.fp.grad.clone().cpu()
+    res["s1.ahead_loss"] = loss.item()
     if rank == 0:
         s_full = student()
         rf = s_full.runtime()

@@ -49,6 +49,10 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     assert rel_l2(r0["s1.grad"], r0["s1.full_grad"]) <= 2e-3
     assert abs(0.5 * (r0["s1.loss"] + r1["s1.loss"]) - r0["s1.full_loss"]) <= 2e-5 * abs(r0["s1.full_loss"])
     assert r0["s1.launched"] == r1["s1.launched"] > 0
+    # ... and with the teacher one batch ahead (TeacherAhead + the planner's shared-GPU setting: split-K plans may differ, values do not)
+    assert torch.equal(r0["s1.ahead_grad"], r1["s1.ahead_grad"])
+    assert rel_l2(r0["s1.ahead_grad"], r0["s1.grad"]) <= 1e-5
+    assert abs(r0["s1.ahead_loss"] - r0["s1.loss"]) <= 2e-6 * abs(r0["s1.loss"])
     # stage 2: one collective per bucket for the whole accumulation step, gradient = full-batch mean-CE gradient
     assert torch.equal(r0["s2.grad"], r1["s2.grad"])
     assert rel_l2(r0["s2.grad"], r0["s2.full_grad"]) <= 2e-3

@@ -87,7 +87,7 @@ class ViTRunner:
         if self._side is None:
             self._side = []
         while len(self._side) <= k:
-            self._side.append(torch.cuda.Stream(device=self.fp.device))
+            self._side.append(torch.cuda.Stream(device=self.fp.device, priority=int(os.environ.get("UNITE_WGRAD_PRIO", "0"))))
         return self._side[k]
 
     def use_slot(self, slot: str) -> None:
