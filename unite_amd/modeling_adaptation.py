@@ -28,6 +28,8 @@ from .flat_params import FlatParams
 from .registry import register_model
 from .vit_runner import ViTRunner, BF16, F32, SPLITK_WS_BYTES
 
+DECODER_STREAM = 4        # index of the runner's side stream the decoders use (0-3: weight gradients)
+
 
 def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
     """pos / 10000^(2*(j//2)/d), sin on even j, cos on odd j (reference modeling_adaptation.py:41-51); (1, n, d) f32."""
@@ -315,7 +317,9 @@ class _StudentRuntime:
         fp.ensure_grad_views()
 
     # -- forward up to the decoder pre-activations
-    def forward_features(self, videos, vis_tokens, n_vis, clip_only, training):
+    def forward_features(self, videos, vis_tokens, n_vis, clip_only, training, tail=None, tail_wait=None):
+        """``tail(k, y_k)`` runs right behind decoder k's projection on whatever stream that ran on (the fused normalise + loss kernel of
+        stage 1); ``tail_wait``: an event the tails have to wait for (the targets)."""
         fp, r, ws = self.fp, self.runner, self.ws
         fp.refresh_if_stale()
         B = videos.shape[0]
@@ -327,27 +331,61 @@ class _StudentRuntime:
         fp.unused_prefixes = tuple(f"encoder.blocks.{i}." for i in range(n_blocks, self.depth))
         dp = r.drop_path_scales(B, training)
         x0 = r.embed(videos, vis_tokens, M)
-        xs = r.blocks_forward(x0, B, n_vis, n_blocks, dp, save=True)
         cpos = ws.get("dec.pos", (M, D), F32)
         ops.gather_rows(self.clip_pos, vis_tokens, cpos, modulo=self.T_N)
-        ys = []
-        self._tap = []
-        for k, li in enumerate(self.taps):
-            xt = xs[li + 1]
+        K = len(self.taps)
+        ys, taps = [None] * K, [None] * K
+        # A decoder reads one tap and nothing reads the decoder before the loss: the decoders of the taps below the last block run on a
+        # side stream while the main stream goes on with the next encoder blocks (0.3 ms of the student's serial chain at B = 32).
+        side = r._side_stream(DECODER_STREAM) if (x0.is_cuda and r.side_decoders) else None
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None and tail_wait is not None:
+            side.wait_event(tail_wait)
+        used_side = [False]
+
+        def decoder(k, xt):
             xn = ws.get(f"dec.xn{k}", (M, D), BF16)
             mean, rstd = ws.get(f"dec.mean{k}", (M,), F32), ws.get(f"dec.rstd{k}", (M,), F32)
             ops.layernorm_fwd(xt, self.norm_w, self.norm_b, self.model.ln_eps, xn, post_add=cpos, mean=mean, rstd=rstd)
             y = ws.get(f"dec.y{k}", (M, C), F32)
             d = self.dec[k]
             ops.gemm(xn, d["w"], y, bias=d["b"])
-            ys.append(y)
-            self._tap.append(dict(x=xt, xn=xn, mean=mean, rstd=rstd, y=y))
+            ys[k] = y
+            taps[k] = dict(x=xt, xn=xn, mean=mean, rstd=rstd, y=y)
+            if tail is not None:
+                tail(k, y)
+
+        def after_block(i, xt):
+            if i not in self.taps:
+                return
+            k = self.taps.index(i)
+            if side is None or i == n_blocks - 1:      # nothing left to run beside it
+                decoder(k, xt)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                decoder(k, xt)
+            used_side[0] = True
+
+        xs = r.blocks_forward(x0, B, n_vis, n_blocks, dp, save=True, after_block=after_block)
+        for k, li in enumerate(self.taps):           # taps above the last executed block (none in the shipped configs)
+            if ys[k] is None:
+                decoder(k, xs[li + 1])
+        if used_side[0]:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+        self._tap = taps
         self._ctx = dict(B=B, n_vis=n_vis, M=M, n_blocks=n_blocks, xs=xs, dp=dp, clip_only=clip_only)
         return ys, xs
 
-    # -- backward from the decoder pre-activation gradients dy_k (bf16 [M,C], already computed into ws "dec.dy{k}")
-    def backward_from_dy(self, dxv: Optional[torch.Tensor] = None):
-        """dxv: optional f32 [M,D] gradient w.r.t. the returned x_vis = encoder.norm(x_out(last)) (clip_only=False)."""
+    # -- backward from the decoder pre-activation gradients dy_k (bf16 [M,C])
+    def backward_from_dy(self, dxv: Optional[torch.Tensor] = None, tail_bwd=None):
+        """dxv: optional f32 [M,D] gradient w.r.t. the returned x_vis = encoder.norm(x_out(last)) (clip_only=False).
+        ``tail_bwd(k, lnws) -> dy_k`` launches the backward of decoder k's tail (norm / loss) on the current stream with the given
+        LayerNorm workspace; without it the dy_k are taken as already computed into ws "dec.dy{k}" on the current stream."""
         fp, r, ws, ctx = self.fp, self.runner, self.ws, self._ctx
         M, D, C, N = ctx["M"], self.D, self.C, ctx["n_vis"]
         acc = fp.accumulate
@@ -355,15 +393,60 @@ class _StudentRuntime:
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, C)))
         csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(r.Hd, 3 * D)))
         gws = ws.bytes_("gemm.ws", SPLITK_WS_BYTES)
-        # decoder heads: dgrad -> gradient of the normalised tap (bf16), wgrad/bias into the flat buffer
-        for k in range(len(self.taps)):
-            d, t = self.dec[k], self._tap[k]
-            dy = ws.peek(f"dec.dy{k}")
+        last = ctx["n_blocks"] - 1
+        K = len(self.taps)
+
+        # decoder k: tail backward -> dgrad (gradient of the normalised tap, bf16) -> wgrad / bias into the flat buffer.  Only the decoder
+        # of the last executed block is needed at once; the others run on the decoders' side stream while the main stream is in the
+        # encoder blocks above their tap, each joined where its tap's gradient enters the chain (tap_grad).
+        def dec_dgrad(k, lnws_k):
+            d = self.dec[k]
+            dy = tail_bwd(k, lnws_k) if tail_bwd is not None else ws.peek(f"dec.dy{k}")
             dxn = ws.get(f"dec.dxn{k}", (M, D), BF16)
             ops.gemm(dy, d["w"], dxn, trans_b=True)
-            ops.gemm(dy, t["xn"], d["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws)      # head bias grad: dysum of the tail
-        if self.layer_done_hook is not None:
-            self.layer_done_hook("clip_decoder")
+            return dy
+
+        def dec_wgrad(k, dy, gws_k):
+            ops.gemm(dy, self._tap[k]["xn"], self.dec[k]["gw"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k)   # head bias grad: dysum of the tail
+
+        order = sorted(range(K), key=lambda k: -self.taps[k])
+        side = r._side_stream(DECODER_STREAM) if (fp.device.type == "cuda" and r.side_decoders and K > 1) else None
+        dec_ev, dec_all = {}, None
+        if side is None:
+            for k in order:
+                dec_wgrad(k, dec_dgrad(k, lnws), gws)
+            if self.layer_done_hook is not None:
+                self.layer_done_hook("clip_decoder")
+        else:
+            main = torch.cuda.current_stream()
+            lnws_d = ws.bytes_("ln.ws.dec", ops.layernorm_bwd_workspace(M, max(D, C)))
+            gws_d = ws.bytes_("gemm.ws.dec", SPLITK_WS_BYTES)
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            side.wait_event(ev0)
+            first = order[0] if self.taps[order[0]] == last else None
+            dy_first, ev_first = None, None
+            if first is not None:
+                dy_first = dec_dgrad(first, lnws)
+                ev_first = torch.cuda.Event()
+                ev_first.record(main)
+            with torch.cuda.stream(side):
+                for k in order:
+                    if k == first:
+                        continue
+                    dy = dec_dgrad(k, lnws_d)
+                    dec_ev[k] = torch.cuda.Event()
+                    dec_ev[k].record(side)
+                    dec_wgrad(k, dy, gws_d)
+                if first is not None:
+                    side.wait_event(ev_first)
+                    dec_wgrad(first, dy_first, gws_d)
+                dec_all = torch.cuda.Event()
+                dec_all.record(side)
+            if self.layer_done_hook is not None:
+                ev_m = torch.cuda.Event()
+                ev_m.record(main)
+                self.layer_done_hook("clip_decoder", (ev_m, dec_all))
         norm_first = [True]
 
         def tap_grad(li, dx_in, scale, dxsum):
@@ -371,6 +454,8 @@ class _StudentRuntime:
             column sums of the bf16 copy (= fc2 bias gradient of block li) into dxsum."""
             k = self.taps.index(li)
             t = self._tap[k]
+            if k in dec_ev:
+                torch.cuda.current_stream().wait_event(dec_ev.pop(k))      # decoder k's dgrad ran on the side stream
             out = ws.get(f"bw.dxt{li & 1}", (M, D), F32)
             outb = ws.get(f"bw.dxtb{li % 3}", (M, D), BF16)      # rotation of 3: read by block li's side-stream weight gradients
             ops.layernorm_bwd(ws.peek(f"dec.dxn{k}"), t["x"], t["mean"], t["rstd"], self.norm_w, dx_residual=dx_in, dx_out=out,
@@ -383,7 +468,6 @@ class _StudentRuntime:
                 self.layer_done_hook("norm")      # encoder.norm's gradient is complete after the lowest tap
             return out, outb
 
-        last = ctx["n_blocks"] - 1
         dx_top = None
         if dxv is not None:      # x_vis = encoder.norm(x_out(depth-1)) was returned and has an upstream gradient
             dx_top = ws.get("bw.dxv", (M, D), F32)
@@ -407,6 +491,8 @@ class _StudentRuntime:
 
         dx0, dx0b = r.blocks_backward(dx, dxb, ctx["n_blocks"], tap_layers=set(self.taps), tap_hook=hook, layer_done=done)
         r.embed_backward(dx0b)
+        if dec_all is not None:
+            torch.cuda.current_stream().wait_event(dec_all)      # the decoders' weight gradients are written before anything reads the flat buffer
         if self.layer_done_hook is not None:
             self.layer_done_hook("patch_embed")
         fp.accumulate = True        # a second backward before zero_grad() adds, as autograd would
@@ -441,16 +527,20 @@ class _StudentFn(torch.autograd.Function):
         M, C = c["M"], rt.C
         dout = grads[0] if ctx.clip_only else grads[1]
         dxv = None if ctx.clip_only else grads[0]
-        lnws = rt.ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(rt.D, C)))
-        for k in range(len(rt.taps)):
+        dout_c = None if dout is None else dout.contiguous()
+        acc = rt.fp.accumulate
+
+        def tail_bwd(k, lnws):
             d = rt.dec[k]
             dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
-            if dout is None:
+            if dout_c is None:
                 dy.zero_()
-                continue
-            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout[k].contiguous().view(M, C), dy,
-                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, dysum=d["gb"])
-        rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D))
+            else:
+                ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout_c[k].view(M, C), dy,
+                                     d["gnw"], d["gnb"], lnws, accumulate=acc, dysum=d["gb"])
+            return dy
+
+        rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D), tail_bwd=tail_bwd)
         return None, None, None, None, None, None
 
 
@@ -460,18 +550,24 @@ class _StudentLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, videos, vis_tokens, n_vis, targets, anchor):
         rt = model.runtime()
-        ys, _ = rt.forward_features(videos, vis_tokens, n_vis, True, model.training)
         M, C, K = videos.shape[0] * n_vis, rt.C, len(rt.taps)
         loss_sum = rt.ws.get("loss.sum", (1,), F32)
         loss_sum.zero_()
-        ev = getattr(rt, "targets_ready", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            rt.targets_ready = None
+        ev = getattr(rt, "targets_ready", None)      # the targets may still be on their way on the teacher's side stream
+        rt.targets_ready = None
         tg = targets.view(K, M, C)
-        for k in range(K):
+        waited = [False]
+
+        def tail(k, y):
+            # normalise + loss of decoder k right behind its projection (same stream); the partial sums meet in loss_sum by float atomics
+            if ev is not None and not waited[0] and torch.cuda.current_stream() == main:
+                main.wait_event(ev)
+                waited[0] = True
             d = rt.dec[k]
-            ops.decoder_tail_fwd(ys[k], d["nw"], d["nb"], model.ln_eps, tg[k], None, loss_sum)
+            ops.decoder_tail_fwd(y, d["nw"], d["nb"], model.ln_eps, tg[k], None, loss_sum)
+
+        main = torch.cuda.current_stream() if videos.is_cuda else None
+        rt.forward_features(videos, vis_tokens, n_vis, True, model.training, tail=tail, tail_wait=ev)
         ctx.model, ctx.targets = model, tg
         return loss_sum[0] / float(K * M)
 
@@ -481,14 +577,17 @@ class _StudentLossFn(torch.autograd.Function):
         rt = model.runtime()
         c = rt._ctx
         M, C, K = c["M"], rt.C, len(rt.taps)
-        lnws = rt.ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(rt.D, C)))
         g = gloss.contiguous().to(F32)
-        for k in range(K):
+        acc, targets = rt.fp.accumulate, ctx.targets
+
+        def tail_bwd(k, lnws):
             d = rt.dec[k]
             dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
-            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, ctx.targets[k], 1.0 / float(K * M), None, dy,
-                                 d["gnw"], d["gnb"], lnws, accumulate=rt.fp.accumulate, loss_scale_dev=g, dysum=d["gb"])
-        rt.backward_from_dy(None)
+            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, targets[k], 1.0 / float(K * M), None, dy,
+                                 d["gnw"], d["gnb"], lnws, accumulate=acc, loss_scale_dev=g, dysum=d["gb"])
+            return dy
+
+        rt.backward_from_dy(None, tail_bwd=tail_bwd)
         return None, None, None, None, None, None
 
 

@@ -73,6 +73,9 @@ class ViTRunner:
         self.wgrad_stream = os.environ.get("UNITE_WGRAD_STREAM", "1") != "0"
         # how many streams the four weight-gradient GEMMs of a block are spread over (1: one after the other)
         self.wgrad_streams = min(4, max(1, int(os.environ.get("UNITE_WGRAD_STREAMS", "1"))))
+        # student decoders on a side stream beside the encoder blocks (modeling_adaptation): shortens the student's serial chain by ~0.6 ms
+        # at B = 32, but with the teacher one batch ahead the GPU is full either way: 20.71 vs 20.55 ms per step without it -> off
+        self.side_decoders = os.environ.get("UNITE_DECODER_STREAM", "0") != "0"
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
         self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
@@ -164,8 +167,10 @@ class ViTRunner:
         ops.gemm(cols, self._pe_w.view(D, Kpe), x0, bias=self._pe_b, residual=pos)
         return x0
 
-    def blocks_forward(self, x0: torch.Tensor, B: int, N: int, n_blocks: int, dp: Optional[torch.Tensor], save: bool) -> List[torch.Tensor]:
-        """Runs blocks 0..n_blocks-1; returns [x0, x_out(0), ..., x_out(n_blocks-1)] (f32 [M, D] each)."""
+    def blocks_forward(self, x0: torch.Tensor, B: int, N: int, n_blocks: int, dp: Optional[torch.Tensor], save: bool,
+                       after_block=None) -> List[torch.Tensor]:
+        """Runs blocks 0..n_blocks-1; returns [x0, x_out(0), ..., x_out(n_blocks-1)] (f32 [M, D] each).  ``after_block(i, x_out)`` is
+        called when block i has been enqueued (the student hangs its decoders there)."""
         self._cache_names()
         D, H, Hd, ws = self.D, self.H, self.Hd, self.ws
         M = B * N
@@ -200,6 +205,8 @@ class ViTRunner:
                                        mean2=mean2, rstd2=rstd2, z=z, a=a))
             xs.append(x2)
             x = x2
+            if after_block is not None:
+                after_block(i, x2)
         self._fw = dict(B=B, N=N, dp=dp)
         return xs
 
