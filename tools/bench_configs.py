@@ -100,8 +100,20 @@ else:
     t_flops = T * (2 * 196 * 588 * 1024 + lin_flops(197, 1024, 24) + attn_flops(197, 1024, 24)) + 6 * 2 * n * 1024 * 768
     flops = 3 * s_f + 2 * (2 * n * 768 * 1024) + t_flops
 
+    import os
+    from unite_amd.engine_stage1 import TeacherAhead, student_phase
+    ahead = TeacherAhead(teacher, st, dev, 0.8, 'attention', clip_input_resolution=196) if os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0" else None
+    touts = []
+
     def step():
-        loss = stage1_step(student, teacher, vid, B, 0.8, 'attention', None, 'mixed', st, clip_input_resolution=196)
+        if ahead is not None:      # the default schedule of train_one_epoch: teacher of the next batch beside the student of this one
+            if not touts:
+                touts.append(ahead.launch(vid))
+            cur = touts.pop()
+            touts.append(ahead.launch(vid))
+            loss = student_phase(student, vid, cur, B, 'mixed')
+        else:
+            loss = stage1_step(student, teacher, vid, B, 0.8, 'attention', None, 'mixed', st, clip_input_resolution=196)
         opt.zero_grad()
         return loss, scaler(loss, opt, clip_grad=None)
     name, units = "stage1 ViT-L/16 student (16fx224^2, 640 visible tokens) + CLIP-L/14 teacher @196", B
