@@ -682,3 +682,36 @@ def test_teacher_ahead_equals_sequential_step():
     assert torch.equal(seq[:, 1], ahd[:, 1]), (seq, ahd)
     torch.testing.assert_close(seq[:, 0], ahd[:, 0], rtol=2e-6, atol=0)
     assert torch.equal(p_seq, p_ahd)
+
+
+def test_train_one_epoch_teacher_ahead_equals_sequential():
+    """train_one_epoch with its default schedule (teacher one batch ahead: the loader is read one batch early, host batches are copied on the
+    teacher's stream, source + target loaders concatenated) against args.teacher_ahead=False (run_stage1.py's order) on the same loaders of
+    host tensors: same meters, bit-identical parameters after the epoch."""
+    from unite_amd.engine_stage1 import train_one_epoch
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
+    steps = 5
+    src = [(make_videos(2, 2, 32, 32, seed=300 + i), torch.full((2,), -1), torch.zeros(2, dtype=torch.long)) for i in range(steps)]
+    tgt = [(make_videos(2, 2, 32, 32, seed=400 + i), torch.full((2,), -1), torch.zeros(2, dtype=torch.long)) for i in range(2)]   # shorter: re-iterated
+    lr = cosine_scheduler(2e-3, 1e-5, 1, steps)
+
+    def run(ahead):
+        s, t = build_tiny()
+        s.load_state_dict(fill_state_dict(student_shapes(TINY_S), 3))
+        t.load_state_dict(fill_state_dict(teacher_shapes(TINY_T), 1))
+        s, t = s.to(DEV), t.to(DEV)
+        args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=2e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95], log_freq=1, epochs=1,
+                               clip_loss_data="mixed", seed=5, teacher_ahead=ahead)
+        opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+        stats = train_one_epoch(s, src, tgt, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), max_norm=None, start_steps=0,
+                                lr_schedule_values=lr, wd_schedule_values=None, teacher_model=t, clip_input_resolution=32,
+                                clip_loss_type='l2', mask_type='attention', mask_ratio=0.5, args=args)
+        torch.cuda.synchronize()
+        return stats, s.runtime().fp.param.clone().cpu()
+
+    st_a, p_a = run(True)
+    st_s, p_s = run(False)
+    assert torch.equal(p_a, p_s)
+    assert st_a["grad_norm"] == st_s["grad_norm"]
+    assert abs(st_a["loss"] - st_s["loss"]) <= 2e-6 * abs(st_s["loss"])
