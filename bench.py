@@ -165,7 +165,17 @@ def main():
         _lib.load().unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
     touts = []
 
+    # experiment: extra HBM traffic on a stream of its own (UNITE_HBM_LOAD = GB copied per step) to see how memory-bound the step is
+    hbm_gb = float(os.environ.get("UNITE_HBM_LOAD", "0"))
+    if hbm_gb > 0:
+        hbm_src = torch.empty(int(hbm_gb * 2 ** 30), dtype=torch.uint8, device=dev)
+        hbm_dst = torch.empty_like(hbm_src)
+        hbm_stream = torch.cuda.Stream(device=dev)
+
     def step():
+        if hbm_gb > 0:
+            with torch.cuda.stream(hbm_stream):
+                hbm_dst.copy_(hbm_src)
         i = it[0]
         for g in opt.param_groups:
             g["lr"] = lr_sched[min(i, len(lr_sched) - 1)] * g["lr_scale"]

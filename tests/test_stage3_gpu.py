@@ -279,6 +279,35 @@ def test_stage3_engine_epoch_updates_encoder_only():
     assert torch.equal(cls.weight.detach(), cls_before)           # A-8: the classifier is used, never optimised
 
 
+def test_stage3_epoch_mask_teacher_ahead_equals_sequential():
+    """engine_stage3.train_one_epoch with the mask teacher one batch ahead on its own stream (default) against args.teacher_ahead=False
+    (run_stage3.py's order), four steps on different host batches: same meters, bit-identical student parameters."""
+    from unite_amd.engine_stage3 import train_one_epoch
+    from unite_amd.optim_factory import create_optimizer
+    from unite_amd.utils import NativeScalerWithGradNormCount
+
+    def run(ahead):
+        s, t, cls, ssd, tsd, d = _setup(seed=1)
+        g = torch.Generator().manual_seed(5)
+        src = [(d["videos_s"] + 0.05 * i, d["labels_s"]) for i in range(4)]
+        tgt = [(d["videos_t"] + 0.03 * i, d["videos_t_aug"] - 0.02 * i, d["labels_t"]) for i in range(3)]
+        args = SimpleNamespace(masking_type="clip_attention", selection_strategy="consORconf", clip_threshold=0.5, conf_weighted_loss=True,
+                               class_loss_tgt_ratio=1.0, class_loss_src_ratio_pl=1.0, class_loss_src_ratio=1e-12, train_masked=True,
+                               full_oracle=False, return_aug_for_val=True, log_freq=1, epochs=1, teacher_ahead=ahead,
+                               opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+        opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
+        stats = train_one_epoch(s, src, tgt, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), max_norm=1.0, src_classifier=cls,
+                                teacher_model=t, mask_ratio=0.75, args=args, clip_input_resolution=64)
+        torch.cuda.synchronize()
+        return stats, s.runtime().fp.param.clone().cpu()
+
+    st_a, p_a = run(True)
+    st_s, p_s = run(False)
+    assert torch.equal(p_a, p_s)
+    for k in ("loss", "loss_class", "loss_class_t", "select_ratio", "grad_norm"):
+        assert abs(st_a[k] - st_s[k]) <= 1e-6 * max(1.0, abs(st_s[k])), k
+
+
 def test_zero_shot_clip_image_side_vs_oracle():
     """utils.clip_infer (src/utils.py:55-68) with the image tower on the HIP kernels: frame embeddings against the oracle's
     restatement of OpenAI CLIP's encode_image (cosine >= 0.999), the similarity kernel against torch on identical inputs (1e-5),

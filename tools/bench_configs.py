@@ -77,8 +77,18 @@ elif a.config == "stage3":
     # per (src, tgt) pair: src fwd+bwd, tgt fwd, committee member 0 fwd, member 1 fwd+bwd, mask teacher fwd
     flops = 3 * full + full + memb + 3 * memb + t_flops
 
+    from unite_amd.engine_stage3 import MaskTeacherAhead
+    ahead = MaskTeacherAhead(teacher, student, dev, 0.8, "clip_attention", res) if os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0" else None
+    mouts = []
+
     def step():
-        loss, *_ = stage3_step(student, teacher, cls, vs, ls, vt, va, lt, args, 0.8, clip_probs_fn=lambda v: probs, clip_input_resolution=res)
+        m = None
+        if ahead is not None:          # the default schedule of engine_stage3.train_one_epoch: mask teacher of the next batch beside this step
+            if not mouts:
+                mouts.append(ahead.launch(va))
+            m = mouts.pop()
+            mouts.append(ahead.launch(va))
+        loss, *_ = stage3_step(student, teacher, cls, vs, ls, vt, va, lt, args, 0.8, clip_probs_fn=lambda v: probs, clip_input_resolution=res, masks=m)
         opt.zero_grad()
         return loss, scaler(loss, opt, clip_grad=None)
     name, units = f"stage3 ViT-B/16 student + {a.teacher} mask teacher, 8fx224^2, B={B} src + {B} tgt (zero-shot CLIP probabilities injected)", B
@@ -100,7 +110,6 @@ else:
     t_flops = T * (2 * 196 * 588 * 1024 + lin_flops(197, 1024, 24) + attn_flops(197, 1024, 24)) + 6 * 2 * n * 1024 * 768
     flops = 3 * s_f + 2 * (2 * n * 768 * 1024) + t_flops
 
-    import os
     from unite_amd.engine_stage1 import TeacherAhead, student_phase
     ahead = TeacherAhead(teacher, st, dev, 0.8, 'attention', clip_input_resolution=196) if os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0" else None
     touts = []

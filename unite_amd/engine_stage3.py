@@ -19,6 +19,7 @@ VisionTransformer.encode_image + unite_clip_similarity); the class text embeddin
 from __future__ import annotations
 
 import math
+import os
 import sys
 import time
 from typing import Callable, Iterable, Optional
@@ -38,6 +39,89 @@ def pool_outputs(outputs, use_cls_token):
     B, N, D = outputs.shape
     out = torch.empty(B, D, dtype=F32, device=outputs.device)
     return ops.token_mean_fwd(outputs.contiguous(), out)
+
+
+def committee_masks(teacher_model, videos_t_aug, masking_type, mask_ratio, clip_input_resolution, N, ws, slot=0):
+    """k = 2 greedy attention-rank masks of the augmented target clips (run_stage3.py:434-506) -> (cmask u8 [k, B*T, N], cvis i32 [k, B*T*n_vis])."""
+    B_t, T = videos_t_aug.shape[0], videos_t_aug.shape[2]
+    if masking_type == "clip_attention":
+        attn_t = teacher_model.forward_attention(teacher_input(teacher_model, videos_t_aug, clip_input_resolution))   # (B_t*T, N)
+    elif masking_type == "random":
+        attn_t = torch.rand(B_t * T, N, device=videos_t_aug.device)                # run_stage3.py:455
+    else:
+        raise NotImplementedError(masking_type)
+    k = 2
+    n_vis_frame = N - int(N * mask_ratio)
+    sfx = "" if slot == 0 else f".{slot}"
+    cmask = ws.get("s3.cmask" + sfx, (k, B_t * T, N), torch.uint8)
+    cvis = ws.get("s3.cvis" + sfx, (k, B_t * T * n_vis_frame), torch.int32)
+    ops.greedy_masks(attn_t, k, cmask, cvis, n_vis_frame)
+    return cmask, cvis
+
+
+class MaskOut:
+    __slots__ = ("cmask", "cvis", "ready", "videos_t_aug")
+
+
+class MaskTeacherAhead:
+    """Stage 3's frozen mask teacher one batch ahead of the student, on a stream of its own (the stage-1 scheme, engine_stage1.TeacherAhead):
+    ``launch(videos_t_aug)`` enqueues the CLIP forward + greedy masks of a batch; the caller then runs the student passes of the PREVIOUS
+    batch.  The teacher's attention depends on nothing the student changes (run_stage3.py:434-451: no_grad, frozen), so every step computes
+    what stage3_step computes.  Three output slots; while it is active the GEMM planner sizes launches for a shared GPU."""
+
+    def __init__(self, teacher_model, student, device, mask_ratio, masking_type, clip_input_resolution):
+        from . import _lib
+        self.teacher, self.ws = teacher_model, getattr(student, "module", student).runtime().ws
+        self.N = getattr(student, "module", student).runtime().frame_tokens
+        self.mask_ratio, self.masking_type, self.res = mask_ratio, masking_type, clip_input_resolution
+        self.stream = torch.cuda.Stream(device=device)
+        self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
+        self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))
+        self.n_slots, self.n, self._marks = 3, 0, []
+        lib = _lib.load()
+        self._sharing_before = lib.unite_gemm_get_sharing()
+        lib.unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
+
+    def close(self):
+        from . import _lib
+        _lib.load().unite_gemm_set_sharing(self._sharing_before)
+
+    def launch(self, videos_t_aug) -> MaskOut:
+        from . import _lib
+        slot = self.n % self.n_slots
+        self.n += 1
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._marks.append(ev)
+        if len(self._marks) > self.n_slots - 1:
+            self._marks.pop(0)
+        self.stream.wait_event(self._marks[0])      # the student step that read this slot was enqueued before that mark
+        if not videos_t_aug.is_cuda:
+            self.stream.wait_event(ev)
+        lib = _lib.load()
+        policy_before = lib.unite_gemm_get_policy()
+        trt = getattr(self.teacher, "module", self.teacher).runtime() if self.masking_type == "clip_attention" else None
+        keep = trt.n_streams if trt is not None else None
+        out = MaskOut()
+        try:
+            if trt is not None:
+                trt.n_streams = self.n_streams
+            with torch.cuda.stream(self.stream):
+                if self.gemm_policy >= 0:
+                    lib.unite_gemm_set_policy(self.gemm_policy)
+                if not videos_t_aug.is_cuda:
+                    videos_t_aug = videos_t_aug.to(self.stream.device, non_blocking=True)
+                out.cmask, out.cvis = committee_masks(self.teacher, videos_t_aug, self.masking_type, self.mask_ratio, self.res, self.N, self.ws, slot)
+                out.ready = torch.cuda.Event()
+                out.ready.record(self.stream)
+                out.videos_t_aug = videos_t_aug
+        finally:
+            if trt is not None:
+                trt.n_streams = keep
+            if self.gemm_policy >= 0:
+                lib.unite_gemm_set_policy(policy_before)
+        return out
 
 
 class _Stage3LossFn(torch.autograd.Function):
@@ -60,19 +144,17 @@ class _Stage3LossFn(torch.autograd.Function):
             ops.linear_f32_fwd(pooled, W, bcls, logits)
             return pooled, logits
 
-        # masks for the committee from the teacher's CLS attention on the augmented target clips
-        if cfg["masking_type"] == "clip_attention":
-            attn_t = teacher_model.forward_attention(teacher_input(teacher_model, videos_t_aug, cfg["clip_input_resolution"]))   # (B_t*T, N)
-        elif cfg["masking_type"] == "random":
-            attn_t = torch.rand(B_t * T, N, device=dev)                               # run_stage3.py:455
-        else:
-            raise NotImplementedError(cfg["masking_type"])
+        # masks for the committee from the teacher's CLS attention on the augmented target clips: computed here, or already under way
+        # on the mask teacher's own stream (MaskTeacherAhead)
         k = 2
         n_vis_frame = N - int(N * cfg["mask_ratio"])
         n_vis = n_vis_frame * T
-        cmask = ws.get("s3.cmask", (k, B_t * T, N), torch.uint8)
-        cvis = ws.get("s3.cvis", (k, B_t * T * n_vis_frame), torch.int32)
-        ops.greedy_masks(attn_t, k, cmask, cvis, n_vis_frame)
+        masks = cfg.get("masks")
+        if masks is None:
+            cmask, cvis = committee_masks(teacher_model, videos_t_aug, cfg["masking_type"], cfg["mask_ratio"], cfg["clip_input_resolution"], N, ws)
+        else:
+            torch.cuda.current_stream().wait_event(masks.ready)
+            cmask, cvis = masks.cmask, masks.cvis
         # student passes
         xv_s = rt.encode(videos_s, None, T * N, "s3src", training, save=True)
         _, logits_s = classify(xv_s, B_s, T * N, "src")
@@ -133,14 +215,18 @@ class _Stage3LossFn(torch.autograd.Function):
 
 
 def stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t, args, mask_ratio,
-                clip_probs_fn: Optional[Callable] = None, clip_input_resolution: Optional[int] = None):
+                clip_probs_fn: Optional[Callable] = None, clip_input_resolution: Optional[int] = None, masks: Optional[MaskOut] = None):
+    """``masks``: the committee masks of this batch if a MaskTeacherAhead already launched them (videos_t_aug is then masks.videos_t_aug)."""
     student = getattr(model, "module", model)
+    if masks is not None:
+        videos_t_aug = masks.videos_t_aug
+        videos_t_aug.record_stream(torch.cuda.current_stream())
     cfg = dict(clip_input_resolution=clip_input_resolution or videos_t_aug.shape[-1],
                masking_type=getattr(args, "masking_type", "clip_attention"), mask_ratio=mask_ratio,
                selection_strategy=getattr(args, "selection_strategy", "clip_matchORconf"), clip_threshold=float(getattr(args, "clip_threshold", 0.5)),
                conf_weighted_loss=bool(getattr(args, "conf_weighted_loss", True)), class_loss_tgt_ratio=float(getattr(args, "class_loss_tgt_ratio", 1.0)),
                class_loss_src_ratio_pl=float(getattr(args, "class_loss_src_ratio_pl", 1.0)), train_masked=bool(getattr(args, "train_masked", True)),
-               full_oracle=bool(getattr(args, "full_oracle", False)), clip_probs_fn=clip_probs_fn)
+               full_oracle=bool(getattr(args, "full_oracle", False)), clip_probs_fn=clip_probs_fn, masks=masks)
     if cfg["selection_strategy"] in ("clip_only", "clip_matchORconf") and clip_probs_fn is None:
         raise NotImplementedError("selection_strategy '%s' needs zero-shot CLIP probabilities: pass clip_probs_fn (the OpenAI CLIP "
                                   "text/image towers of utils.setup_clip are outside the built path)" % cfg["selection_strategy"])
@@ -183,14 +269,9 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                 sys.exit(1)
             metric_logger.update(loss=lv, loss_class=ls, loss_class_t=lt, select_ratio=sr, grad_norm=gn)
 
-    for step, batch in enumerate(metric_logger.log_every(data_loader, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
-        it = start_steps + step
-        if lr_schedule_values is not None or wd_schedule_values is not None:
-            for param_group in optimizer.param_groups:
-                if lr_schedule_values is not None:
-                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
-                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
-                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
+    def prepare(batch):
+        """one iteration's source + target batch (:396-431) -> (videos_s, labels_s, videos_t, videos_t_aug, labels_t), still where the loaders put them"""
+        nonlocal tgt_iter
         videos_s, labels_s = batch[0], batch[1]
         try:
             tb = next(tgt_iter)
@@ -202,11 +283,48 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
             videos_t_aug, labels_t = tb[1], tb[2]
         else:
             videos_t_aug, labels_t = tb[0], tb[1]          # the reference would fail on cat(None) here (:413); use the clip itself
-        videos_s, videos_t, videos_t_aug = (v.to(device, non_blocking=True) for v in (videos_s, videos_t, videos_t_aug))
+        return videos_s, labels_s, videos_t, videos_t_aug, labels_t
+
+    # mask teacher one batch ahead (default on a GPU; args.teacher_ahead=False / UNITE_TEACHER_AHEAD=0: the order of run_stage3.py)
+    ahead_on = getattr(args, "teacher_ahead", None)
+    if ahead_on is None:
+        ahead_on = os.environ.get("UNITE_TEACHER_AHEAD", "1") != "0"
+    ahead_on = bool(ahead_on) and torch.device(device).type == "cuda"
+    masking_type = getattr(args, "masking_type", "clip_attention")
+    ahead = MaskTeacherAhead(teacher_model, model, device, mask_ratio, masking_type, clip_input_resolution) if ahead_on else None
+
+    class _Ahead:
+        def __len__(self):
+            return len(data_loader)
+
+        def __iter__(self):
+            prev = None
+            for batch in data_loader:
+                cur = prepare(batch)
+                m = ahead.launch(cur[3])
+                if prev is not None:
+                    yield prev
+                prev = (cur, m)
+            if prev is not None:
+                yield prev
+
+    source = _Ahead() if ahead_on else data_loader
+    for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
+        it = start_steps + step
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
+                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
+        (videos_s, labels_s, videos_t, videos_t_aug, labels_t), masks = item if ahead_on else (prepare(item), None)
+        videos_s, videos_t = videos_s.to(device, non_blocking=True), videos_t.to(device, non_blocking=True)
+        if masks is None:
+            videos_t_aug = videos_t_aug.to(device, non_blocking=True)
         labels_s, labels_t = labels_s.to(device, non_blocking=True), labels_t.to(device, non_blocking=True)
 
         loss, loss_s, loss_t, sel = stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t,
-                                                args, mask_ratio, clip_probs_fn, clip_input_resolution)
+                                                args, mask_ratio, clip_probs_fn, clip_input_resolution, masks=masks)
         optimizer.zero_grad()
         grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
         pending.append((loss, loss_s, loss_t, sel.float().mean(), grad_norm))
@@ -222,6 +340,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
         metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)
+    if ahead is not None:
+        ahead.close()
     flush()
     metric_logger.synchronize_between_processes()
     print(f"[{time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())}] Averaged stats:", metric_logger)
