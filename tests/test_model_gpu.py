@@ -715,3 +715,27 @@ def test_train_one_epoch_teacher_ahead_equals_sequential():
     assert torch.equal(p_a, p_s)
     assert st_a["grad_norm"] == st_s["grad_norm"]
     assert abs(st_a["loss"] - st_s["loss"]) <= 2e-6 * abs(st_s["loss"])
+
+
+def test_decoders_on_side_stream_bit_identical():
+    """ViTRunner.side_decoders (UNITE_DECODER_STREAM=1: the student's decoders -- projection, fused normalise + loss, their backward -- on a side
+    stream beside the encoder blocks; off by default) gives bit-identical gradients to the one-stream order, twice in a row (buffer reuse)."""
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    vid = make_videos(4, 2, 32, 32, seed=77).to(DEV)
+    imp = make_importance(8, 4, seed=78).to(DEV)
+    grads = []
+    for on in (False, True):
+        s, t = build_tiny()
+        s.load_state_dict(fill_state_dict(student_shapes(TINY_S), 3))
+        t.load_state_dict(fill_state_dict(teacher_shapes(TINY_T), 1))
+        s, t = s.to(DEV).train(), t.to(DEV)
+        rt = s.runtime()
+        rt.runner.side_decoders = on
+        for _ in range(2):
+            rt.fp.accumulate = False
+            loss = stage1_step(s, t, vid, 4, 0.5, 'attention', None, 'mixed', StepState(), clip_input_resolution=32, importance=imp)
+            loss.backward()
+            torch.cuda.synchronize()
+        grads.append(rt.fp.grad.clone())
+        assert torch.isfinite(loss).item()
+    assert torch.equal(grads[0], grads[1])
