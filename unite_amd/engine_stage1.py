@@ -32,7 +32,7 @@ class StepState:
         self.mask = None                 # the buffers of the slot used last (tests read them)
         self.vis = None
         self.rows = None
-        self.slots = {}                  # slot -> (mask, vis, rows): two slots when the teacher runs one batch ahead
+        self.slots = {}                  # slot -> (mask, vis, rows): three slots when the teacher runs ahead of the student (TeacherAhead)
         self.seed = 0
         self.step_params = None          # graph_step.StepParams: the mask sampler then reads its seed from device memory
         self.overlap_targets = os.environ.get("UNITE_OVERLAP_TARGETS", "1") != "0"
@@ -150,7 +150,7 @@ class TeacherAhead:
     its own and returns its TeacherOut; the caller then trains the student on the PREVIOUS batch, whose teacher phase was launched an
     iteration earlier.  Nothing in the teacher depends on the student (frozen, no_grad: run_stage1.py:371), so the arithmetic of every
     step is that of stage1_step; what changes is that the student's many short, partially filled launches (and, on N GPUs, its gradient
-    all-reduces) share the GPU with the teacher's long GEMMs.  Outputs alternate between two slots.
+    all-reduces) share the GPU with the teacher's long GEMMs.  Outputs rotate through ``n_slots`` (three) slots.
 
     Measured on MI355X (B = 32): 23.7 -> 21.6 ms per step, 20.4 with the GEMM planner told that launches share the
     GPU (unite_gemm_set_sharing: larger tiles, fewer split-K slices).  Beside a concurrent student the teacher is best left on ONE
@@ -183,9 +183,10 @@ class TeacherAhead:
         slot = self.n % self.n_slots
         self.n += 1
         main = torch.cuda.current_stream()
-        # Slot reuse: this launch overwrites the outputs read by the student step n_slots launches back.  That step was enqueued before the
-        # launch n_slots - 2 calls ago, so the mark recorded THEN is late enough -- with three slots the teacher may start on batch i+1
-        # while the student is still on batch i-1, and neither stream waits for the other at every step (with two slots: mark of this call).
+        # Slot reuse: launch k overwrites the outputs of launch k - n_slots, read by student step k - n_slots.  A mark recorded at launch j
+        # has every student step <= j - 2 in front of it (step j - 1 is enqueued right after launch j), so the mark of launch
+        # k - n_slots + 2 is late enough: the oldest of the n_slots - 1 marks kept.  With three slots the teacher may start on batch i+1
+        # while the student is still on batch i-1, and neither stream waits for the other at every step (two slots: the mark of this call).
         ev = torch.cuda.Event()
         ev.record(main)
         self._marks.append(ev)
