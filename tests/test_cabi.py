@@ -36,6 +36,21 @@ def test_ctypes_table_matches_header():
     assert ctypes.sizeof(_lib.GemmArgs) % 8 == 0 and len(_lib.GemmArgs._fields_) == 29
 
 
+def test_comm_header_symbols_are_exported():
+    """include/unite_comm.h (the RCCL side of SURVEY 8b: unite_comm_{init,allreduce_bucket,broadcast,destroy}) against libunite_comm.so and
+    the ctypes table; loading it needs librccl, no GPU"""
+    from unite_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "unite_comm.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(unite_comm_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(_lib.COMM_SIGNATURES) and {"unite_comm_init", "unite_comm_allreduce_bucket", "unite_comm_broadcast",
+                                                      "unite_comm_destroy"} <= set(names)
+    assert os.path.exists(_lib.COMM_LIB_PATH), "build with `make -C unite_amd/csrc`"
+    lib = _lib.load_comm()
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.unite_comm_world() == 0                     # no communicator before unite_comm_init
+
+
 def test_workspace_queries_run_without_gpu():
     from unite_amd import ops
     assert ops.layernorm_bwd_workspace(10240, 768) == (10240 // 16) * 3 * 768 * 4

@@ -123,6 +123,42 @@ def load() -> C.CDLL:
     return lib
 
 
+# ---- the collective side: include/unite_comm.h -> unite_amd/lib/libunite_comm.so (links RCCL; loaded on demand only)
+COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libunite_comm.so")
+COMM_ID_BYTES = 128
+COMM_SIGNATURES = {
+    "unite_comm_unique_id": (c_i, [c_p, c_sz]),
+    "unite_comm_init": (c_i, [c_i, c_i, c_p, c_sz]),
+    "unite_comm_allreduce_bucket": (c_i, [c_p, c_i64, c_i, c_i, c_p]),
+    "unite_comm_broadcast": (c_i, [c_p, c_i64, c_i, c_p]),
+    "unite_comm_world": (c_i, []),
+    "unite_comm_rank": (c_i, []),
+    "unite_comm_destroy": (c_i, []),
+}
+_comm = None
+
+
+def load_comm() -> C.CDLL:
+    """Load libunite_comm.so (RCCL behind the C ABI of include/unite_comm.h); raises if it is missing."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    if not os.path.exists(COMM_LIB_PATH):
+        raise UniteHipError(f"{COMM_LIB_PATH} not found: build it with `make -C unite_amd/csrc`")
+    lib = C.CDLL(COMM_LIB_PATH)
+    for name, (res, args) in COMM_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _comm = lib
+    return lib
+
+
+def check_comm(code: int, what: str) -> None:
+    if code != 0:
+        raise UniteHipError(f"{what} failed: " + ("bad argument / communicator state" if code < 0 else f"ncclResult_t {code - 1000}"))
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         kind = {-1: "UNITE_EINVAL (bad shape/alignment/null pointer)", -2: "UNITE_ENOSUP (unsupported shape)"}.get(

@@ -15,11 +15,29 @@ how the N > 1 path is tested with gloo on CPU.
 from __future__ import annotations
 
 import contextlib
+import ctypes
+import os
 from typing import Dict, Hashable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+
+def native_comm(group=None):
+    """The process-wide RCCL communicator behind include/unite_comm.h, created on first use: rank 0 draws the rendezvous id and the
+    launcher's process group carries it to the other ranks (one object broadcast).  Returns the bound library."""
+    from . import _lib
+    lib = _lib.load_comm()
+    if lib.unite_comm_world() == 0:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank == 0:
+            _lib.check_comm(lib.unite_comm_unique_id(buf, _lib.COMM_ID_BYTES), "unite_comm_unique_id")
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=0, group=group)
+        _lib.check_comm(lib.unite_comm_init(rank, world, box[0], _lib.COMM_ID_BYTES), "unite_comm_init")
+    return lib
 
 
 class GradReducer:
@@ -62,6 +80,12 @@ class GradReducer:
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.use_stream else None
         # RCCL ('nccl') averages in the collective; gloo (CPU tests, single-GPU rehearsal) has no AVG: sum, then scale
         self.native_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # UNITE_COMM_NATIVE=1: the buckets go through libunite_comm.so (unite_comm_allreduce_bucket, include/unite_comm.h) instead of
+        # torch.distributed's nccl backend -- the same RCCL underneath, without the process-group layer per collective.  Opt-in: its
+        # multi-rank path has not run on hardware yet (one GPU per box here; tests/test_comm_gpu.py covers the one-rank communicator).
+        self.comm = None
+        if self.use_stream and self.world > 1 and self.native_avg and os.environ.get("UNITE_COMM_NATIVE", "0") == "1":
+            self.comm = native_comm(group)
         self._pending: List[set] = []
         self._events: List[list] = []
         self._works = []
@@ -113,8 +137,13 @@ class GradReducer:
         if self.use_stream and self.native_avg:
             for ev in self._events[i]:
                 self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+            if self.comm is not None:
+                from . import _lib
+                _lib.check_comm(self.comm.unite_comm_allreduce_bucket(view.data_ptr(), view.numel(), 0, 1, self.stream.cuda_stream),
+                                "unite_comm_allreduce_bucket")
+            else:
+                with torch.cuda.stream(self.stream):
+                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
         else:
             if self.use_stream:          # gloo on device tensors stages through the host from the CURRENT stream
                 for ev in self._events[i]:
