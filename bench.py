@@ -37,8 +37,10 @@ PEAK_BF16 = 2.5e15            # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-
 GF_STUDENT, GF_TEACHER = 179.7e9, 282.5e9     # algorithmic FLOPs per clip, BASELINE.md section 2
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """oracle stage-1 step (teacher fwd, student fwd+bwd, grad-norm, AdamW) at BASELINE configs[0] (B=4), fp32, all host cores."""
+def cpu_baseline(seconds_budget=30.0):
+    """oracle stage-1 step (teacher fwd, student fwd+bwd, grad-norm, AdamW), fp32, the box's host cores: BASELINE configs[0] (B = 4, the
+    reference's own CPU-runnable case) for a few steps, then ONE step at the benchmark's own batch (B = 32, configs[1]) if the budget allows
+    -- `value` is the B = 32 rate when that step ran, the B = 4 rate otherwise; `sample` says which and quotes both."""
     from oracle import umt_oracle as O
     from oracle.filler import fill_state_dict, make_importance, make_videos
     from tests.shapes import student_shapes, teacher_shapes
@@ -53,12 +55,17 @@ def cpu_baseline(seconds_budget=25.0):
     ssd = fill_state_dict(student_shapes(scfg), 12)
     tsd = fill_state_dict(teacher_shapes(tcfg), 11)
     B = 4
-    vid = make_videos(B, 8, 224, 224, 13)
-    mask = O.mask_from_importance(make_importance(B * 8, 196, 14), 40, B)
+    data = {}
+
+    def batch(Bn):
+        if Bn not in data:
+            data[Bn] = (make_videos(Bn, 8, 224, 224, 13), O.mask_from_importance(make_importance(Bn * 8, 196, 14), 40, Bn))
+        return data[Bn]
     m = {k: torch.zeros_like(v) for k, v in ssd.items()}
     v = {k: torch.zeros_like(v) for k, v in ssd.items()}
 
-    def step(i):
+    def step(i, Bn=4):
+        vid, mask = batch(Bn)
         leaf = {k: p.requires_grad_(True) for k, p in ssd.items()}
         loss, *_ = O.stage1_loss(leaf, tsd, vid, mask, scfg, tcfg)
         loss.backward()
@@ -66,21 +73,29 @@ def cpu_baseline(seconds_budget=25.0):
         with torch.no_grad():
             for k, p in leaf.items():
                 p.requires_grad_(False)
-                O.adamw_step(p, p.grad, m[k], v[k], i, 1.5e-4 * B / 256, 0.9, 0.95, 1e-8, 0.05 if p.ndim > 1 else 0.0)
+                O.adamw_step(p, p.grad, m[k], v[k], i, 1.5e-4 * Bn / 256, 0.9, 0.95, 1e-8, 0.05 if p.ndim > 1 else 0.0)
                 p.grad = None
 
     t0 = time.time()
     step(1)                                   # warm-up
     warm = time.time() - t0
     print(f"[bench] cpu baseline warm-up step: {warm:.1f} s on {threads} threads", file=sys.stderr, flush=True)
-    n = max(1, min(6, int((seconds_budget - warm) / max(warm, 1e-3))))
+    n = 2
     t0 = time.time()
     for i in range(n):
         step(2 + i)
     dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{n} timed stage-1 steps at B={B} (8fx224^2, ViT-B/16 + CLIP-B/16, fp32 torch CPU oracle) after 1 warm-up; "
-                      f"{dt:.2f} s/step"}
+    sample = f"{n} timed stage-1 steps at B={B} (8fx224^2, ViT-B/16 + CLIP-B/16, fp32 torch CPU oracle) after 1 warm-up: {dt:.2f} s/step = {B / dt:.2f} clips/s"
+    value = B / dt
+    spent = warm + n * dt
+    if spent + 8.5 * dt <= seconds_budget + 5.0:          # one step at the benchmark's batch: ~8x the B = 4 step
+        batch(32)
+        t0 = time.time()
+        step(2 + n, 32)
+        dt32 = time.time() - t0
+        value = 32 / dt32
+        sample = f"1 timed stage-1 step at B=32 (the benchmark's batch): {dt32:.1f} s = {value:.2f} clips/s; before it " + sample
+    return {"value": round(value, 3), "unit": "clips/s", "cores": threads, "kind": "port", "sample": sample}
 
 
 def main():
