@@ -684,7 +684,8 @@ def test_teacher_ahead_equals_sequential_step():
     assert torch.equal(p_seq, p_ahd)
 
 
-def test_train_one_epoch_teacher_ahead_equals_sequential():
+@pytest.mark.parametrize("mask_type", ["attention", "tube"])
+def test_train_one_epoch_teacher_ahead_equals_sequential(mask_type):
     """train_one_epoch with its default schedule (teacher one batch ahead: the loader is read one batch early, host batches are copied on the
     teacher's stream, source + target loaders concatenated) against args.teacher_ahead=False (run_stage1.py's order) on the same loaders of
     host tensors: same meters, bit-identical parameters after the epoch."""
@@ -692,8 +693,13 @@ def test_train_one_epoch_teacher_ahead_equals_sequential():
     from unite_amd.optim_factory import create_optimizer
     from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
     steps = 5
-    src = [(make_videos(2, 2, 32, 32, seed=300 + i), torch.full((2,), -1), torch.zeros(2, dtype=torch.long)) for i in range(steps)]
-    tgt = [(make_videos(2, 2, 32, 32, seed=400 + i), torch.full((2,), -1), torch.zeros(2, dtype=torch.long)) for i in range(2)]   # shorter: re-iterated
+    g = torch.Generator().manual_seed(9)
+
+    def tube(B):          # loader-side masks (mask_type 'tube': run_stage1.py:344-358): one spatial pattern per clip, half of the 4 patches visible
+        fm = torch.stack([torch.randperm(4, generator=g) >= 2 for _ in range(B)])
+        return fm[:, None, :].expand(B, 2, 4).reshape(B, 8).contiguous()
+    src = [(make_videos(2, 2, 32, 32, seed=300 + i), tube(2), torch.zeros(2, dtype=torch.long)) for i in range(steps)]
+    tgt = [(make_videos(2, 2, 32, 32, seed=400 + i), tube(2), torch.zeros(2, dtype=torch.long)) for i in range(2)]   # shorter: re-iterated
     lr = cosine_scheduler(2e-3, 1e-5, 1, steps)
 
     def run(ahead):
@@ -706,7 +712,7 @@ def test_train_one_epoch_teacher_ahead_equals_sequential():
         opt = create_optimizer(args, s, skip_list=s.no_weight_decay())
         stats = train_one_epoch(s, src, tgt, opt, torch.device(DEV), 0, NativeScalerWithGradNormCount(), max_norm=None, start_steps=0,
                                 lr_schedule_values=lr, wd_schedule_values=None, teacher_model=t, clip_input_resolution=32,
-                                clip_loss_type='l2', mask_type='attention', mask_ratio=0.5, args=args)
+                                clip_loss_type='l2', mask_type=mask_type, mask_ratio=0.5, args=args)
         torch.cuda.synchronize()
         return stats, s.runtime().fp.param.clone().cpu()
 
