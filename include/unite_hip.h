@@ -343,6 +343,13 @@ int unite_linear_f32_bwd(const float* x, const float* W, const float* dy, float*
 int unite_softmax_ce(const float* logits, const int64_t* labels, const float* row_weight, float grad_scale,
                      float* loss_sum, float* dlogits, int32_t M, int32_t C, void* stream);
 
+/* The other three clip_loss_type options of stage 1 (run_stage1.py:403-408,431-434: nn.MSELoss / nn.L1Loss / nn.SmoothL1Loss on the
+ * normalised decoder outputs; every shipped config uses 'l2', which is fused into unite_decoder_tail_*):
+ *   loss_sum += sum_i f(out_i - target_i),  grad_i = grad_scale * f'(out_i - target_i)   (the caller passes grad_scale = 1 / n for the mean)
+ * kind 0 = mse (d^2), 1 = l1 (|d|), 2 = smooth_l1 (Huber, beta = 1).  n % 4 == 0, 16-byte aligned pointers; grad may be NULL. */
+int unite_pointwise_loss(const float* out, const float* target, int32_t kind, float grad_scale, float* loss_sum, float* grad,
+                         int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

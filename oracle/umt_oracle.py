@@ -312,9 +312,12 @@ def gather_targets(norm_clip: Tensor, mask: Tensor) -> Tensor:
     return norm_clip[~m].reshape(K, B, -1, C)
 
 
-def umt_loss(outputs_clip: Tensor, targets_clip: Tensor) -> Tensor:
-    """clip_loss_type == 'l2' (run_stage1.py:431)."""
-    return (2 - 2 * (outputs_clip * targets_clip).sum(dim=-1)).mean()
+def umt_loss(outputs_clip: Tensor, targets_clip: Tensor, clip_loss_type: str = "l2") -> Tensor:
+    """run_stage1.py:403-408,431-436: 'l2' (every shipped config) or nn.MSELoss / nn.SmoothL1Loss / nn.L1Loss on the same tensors."""
+    if clip_loss_type == "l2":
+        return (2 - 2 * (outputs_clip * targets_clip).sum(dim=-1)).mean()
+    fn = {"mse": F.mse_loss, "smooth_l1": F.smooth_l1_loss, "l1": F.l1_loss}[clip_loss_type]
+    return fn(input=outputs_clip, target=targets_clip)
 
 
 def teacher_resize(videos: Tensor, resolution: int) -> Tensor:
@@ -327,13 +330,13 @@ def teacher_resize(videos: Tensor, resolution: int) -> Tensor:
 
 
 def stage1_loss(student_sd: SD, teacher_sd: SD, videos: Tensor, mask: Tensor,
-                scfg: StudentCfg, tcfg: TeacherCfg):
+                scfg: StudentCfg, tcfg: TeacherCfg, clip_loss_type: str = "l2"):
     """teacher -> gather -> student -> loss for an explicit mask (clip_loss_data='mixed')."""
     with torch.no_grad():
         feats, attn = teacher_forward(teacher_sd, teacher_resize(videos, tcfg.input_resolution), tcfg, return_attn=True)
         tgt = gather_targets(feats, mask)
     out = student_forward(student_sd, videos, mask, scfg, clip_only=True)
-    return umt_loss(out, tgt), out, tgt, attn
+    return umt_loss(out, tgt, clip_loss_type), out, tgt, attn
 
 
 # --------------------------------------------------------------------------

@@ -94,6 +94,7 @@ SIGNATURES = {
     "unite_linear_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_linear_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_softmax_ce": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
+    "unite_pointwise_loss": (c_i, [c_p, c_p, c_i, C.c_float, c_p, c_p, c_i64, c_p]),
 }
 
 _lib: Optional[C.CDLL] = None

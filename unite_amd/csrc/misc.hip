@@ -768,6 +768,43 @@ extern "C" int unite_linear_f32_bwd(const float* x, const float* W, const float*
     return UNITE_OK;
 }
 
+// ------------------------------------------------------------------------------------ element-wise regression losses (clip_loss_type)
+// loss_sum += sum_i f(o_i - t_i);  grad_i = grad_scale * f'(o_i - t_i)   with f = d^2 (0: mse), |d| (1: l1), Huber beta = 1 (2: smooth_l1)
+__global__ __launch_bounds__(256) void pointwise_loss_kernel(const float* __restrict__ o, const float* __restrict__ t, int kind, float grad_scale,
+                                                             float* __restrict__ loss_sum, float* __restrict__ grad, size_t n4) {
+    __shared__ float wl[4];
+    float l = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = ((const f32x4*)o)[i], b = ((const f32x4*)t)[i];
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = a[e] - b[e], ad = fabsf(d), sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            if (kind == 0) { l += d * d; g[e] = 2.f * d; }
+            else if (kind == 1) { l += ad; g[e] = sg; }
+            else { l += ad < 1.f ? 0.5f * d * d : ad - 0.5f; g[e] = ad < 1.f ? d : sg; }
+            g[e] *= grad_scale;
+        }
+        if (grad) ((f32x4*)grad)[i] = g;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m);
+    if ((threadIdx.x & 63) == 0) wl[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, wl[0] + wl[1] + wl[2] + wl[3]);
+}
+
+extern "C" int unite_pointwise_loss(const float* out, const float* target, int32_t kind, float grad_scale, float* loss_sum, float* grad,
+                                    int64_t n, void* stream) {
+    if (!out || !target || kind < 0 || kind > 2 || n <= 0 || (n & 3) || (((uintptr_t)out | (uintptr_t)target | (uintptr_t)grad) & 15))
+        return UNITE_EINVAL;
+    const size_t n4 = (size_t)n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pointwise_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, target, kind, grad_scale, loss_sum, grad, n4);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
 extern "C" int unite_softmax_ce(const float* logits, const int64_t* labels, const float* row_weight, float grad_scale, float* loss_sum,
                                 float* dlogits, int32_t M, int32_t C, void* stream) {
     if (!logits || !labels || M <= 0 || C <= 0 || C > 1024) return UNITE_EINVAL;

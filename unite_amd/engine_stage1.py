@@ -103,8 +103,29 @@ def teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos,
     return out
 
 
-def student_phase(model, videos, tout: TeacherOut, n_source, clip_loss_data):
-    """student forward on the visible tokens + decoders + UMT loss (run_stage1.py:410-438).  Returns the 0-dim loss (with grad_fn)."""
+class _PointwiseLoss(torch.autograd.Function):
+    """mean over all elements of f(outputs_clip - targets_clip): nn.MSELoss / nn.L1Loss / nn.SmoothL1Loss of run_stage1.py:403-408,433-434
+    in one kernel that also leaves the gradient (unite_pointwise_loss)."""
+
+    @staticmethod
+    def forward(ctx, out, target, kind):
+        out = out.contiguous()
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=out.device)
+        grad = torch.empty_like(out)
+        ops.pointwise_loss(out, target.contiguous().view_as(out), kind, loss_sum, grad, 1.0 / out.numel())
+        ctx.save_for_backward(grad)
+        return loss_sum[0] / out.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def student_phase(model, videos, tout: TeacherOut, n_source, clip_loss_data, clip_loss_type='l2'):
+    """student forward on the visible tokens + decoders + UMT loss (run_stage1.py:410-438).  Returns the 0-dim loss (with grad_fn).
+    clip_loss_type 'l2' (every shipped config) is fused into the decoders' tail kernel; 'mse' / 'l1' / 'smooth_l1' go through the decoder
+    outputs (K, B, n_vis, C) and unite_pointwise_loss."""
     B, C, T, H, W = videos.shape
     n_vis, targets, ready = tout.n_vis, tout.targets, tout.ready
     if tout.foreign and ready is not None:         # the whole teacher phase ran on another stream: the token list is needed first
@@ -134,15 +155,28 @@ def student_phase(model, videos, tout: TeacherOut, n_source, clip_loss_data):
         targets = targets.view(K, B, n_vis, -1)[:, lo:hi].contiguous().view(K * (hi - lo) * n_vis, -1)
         videos_l = videos[lo:hi].contiguous()
         vis_l = (tout.vis.view(B, n_vis)[lo:hi] - lo * T * N).contiguous().view(-1)
+        if clip_loss_type != 'l2':
+            return _other_clip_loss(model, videos_l, vis_l, n_vis, targets, clip_loss_type)
         return model.forward_loss(videos_l, vis_l, n_vis, targets)
+    if clip_loss_type != 'l2':
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+        return _other_clip_loss(model, videos, tout.vis, n_vis, targets, clip_loss_type)
     return model.forward_loss(videos, tout.vis, n_vis, targets, targets_ready=ready)
 
 
+def _other_clip_loss(model, videos, vis, n_vis, targets, clip_loss_type):
+    if clip_loss_type not in ops.POINTWISE_LOSS:
+        raise NotImplementedError(f"clip_loss_type={clip_loss_type!r} (run_stage1.py:432-436 knows l2, mse, smooth_l1, l1)")
+    out = model(videos, None, clip_only=True, vis_tokens=vis, n_vis=n_vis)          # (K, B, n_vis, C), L2-normalised rows
+    return _PointwiseLoss.apply(out, targets, clip_loss_type)
+
+
 def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state: StepState,
-                clip_input_resolution=224, importance=None):
+                clip_input_resolution=224, importance=None, clip_loss_type='l2'):
     """teacher -> mask -> targets -> student loss (device tensors only).  Returns the 0-dim loss tensor (with grad_fn)."""
     tout = teacher_phase(teacher_model, videos, mask_ratio, mask_type, bool_masked_pos, state, clip_input_resolution, importance)
-    return student_phase(model, videos, tout, n_source, clip_loss_data)
+    return student_phase(model, videos, tout, n_source, clip_loss_data, clip_loss_type)
 
 
 class TeacherAhead:
@@ -245,8 +279,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                     log_writer=None, lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
                     src_classifier=None, teacher_model=None, clip_input_resolution=224, clip_loss_type='l2', clip_loss_ratio=0.5,
                     mask_type='tube', mask_ratio=0., use_wandb=False, args=None):
-    if clip_loss_type != 'l2':
-        raise NotImplementedError("only clip_loss_type='l2' (every UNITE config) is built")
+    if clip_loss_type != 'l2' and clip_loss_type not in ops.POINTWISE_LOSS:
+        raise NotImplementedError(f"clip_loss_type={clip_loss_type!r} (run_stage1.py:432-436 knows l2, mse, smooth_l1, l1)")
     if src_classifier is not None:
         raise NotImplementedError("stage 1 is run with src_classifier=None (run_stage1.py:858)")
     model.train()
@@ -326,11 +360,11 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
         if ahead_on:
             (_, bool_masked_pos, B_s), tout = item
             videos = tout.videos
-            loss = student_phase(model, videos, tout, B_s, clip_loss_data)
+            loss = student_phase(model, videos, tout, B_s, clip_loss_data, clip_loss_type)
         else:
             videos, bool_masked_pos, B_s = prepare(item)
             loss = stage1_step(model, teacher_model, videos, B_s, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state,
-                               clip_input_resolution)
+                               clip_input_resolution, clip_loss_type=clip_loss_type)
         optimizer.zero_grad()
         grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
         pending.append((loss, grad_norm))

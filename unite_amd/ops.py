@@ -394,6 +394,19 @@ def softmax_ce(logits, labels, loss_sum, dlogits=None, row_weight=None, grad_sca
                "unite_softmax_ce")
 
 
+POINTWISE_LOSS = {"mse": 0, "l1": 1, "smooth_l1": 2}
+
+
+def pointwise_loss(out, target, kind: str, loss_sum, grad=None, grad_scale: float = 1.0):
+    """loss_sum += sum f(out - target), grad = grad_scale * f'(out - target); kind in mse / l1 / smooth_l1 (run_stage1.py:403-408)."""
+    lib = _lib.load()
+    _req(out, F32, "out"); _req(target, F32, "target")
+    if out.numel() != target.numel() or not out.is_contiguous() or not target.is_contiguous():
+        raise ValueError("pointwise_loss needs contiguous tensors of equal size")
+    _lib.check(lib.unite_pointwise_loss(_ptr(out), _ptr(target), POINTWISE_LOSS[kind], grad_scale, _ptr(loss_sum), _ptr(grad), out.numel(),
+                                        _stream()), "unite_pointwise_loss")
+
+
 def linear_f32_fwd(x, W, bias, y):
     lib = _lib.load()
     B, D = x.shape
