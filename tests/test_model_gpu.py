@@ -673,6 +673,8 @@ def test_teacher_ahead_equals_sequential_step():
             torch.cuda.current_stream().synchronize()                  # the slot's mask is overwritten two launches later
             masks.append(m.clone().cpu())
         torch.cuda.synchronize()
+        if ahead is not None:
+            ahead.close()
         return torch.stack(out).cpu(), s.runtime().fp.param.clone().cpu(), torch.stack(masks)
 
     seq, p_seq, m_seq = run(False)

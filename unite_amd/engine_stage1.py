@@ -207,9 +207,23 @@ class TeacherAhead:
         self._marks = []                   # events on the student's stream, one per launch
 
     def close(self):
-        """back to the planner setting found at construction (the launches already enqueued keep theirs)"""
-        from . import _lib
-        _lib.load().unite_gemm_set_sharing(self._sharing_before)
+        """back to the planner setting found at construction (the launches already enqueued keep theirs); idempotent"""
+        if self._sharing_before is not None:
+            from . import _lib
+            _lib.load().unite_gemm_set_sharing(self._sharing_before)
+            self._sharing_before = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def launch(self, videos, bool_masked_pos=None, importance=None) -> TeacherOut:
         """``videos`` may still be on the host: the copy then goes on the teacher's stream too (TeacherOut.videos is the device tensor)."""

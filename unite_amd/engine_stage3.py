@@ -83,8 +83,16 @@ class MaskTeacherAhead:
         lib.unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
 
     def close(self):
-        from . import _lib
-        _lib.load().unite_gemm_set_sharing(self._sharing_before)
+        if self._sharing_before is not None:
+            from . import _lib
+            _lib.load().unite_gemm_set_sharing(self._sharing_before)
+            self._sharing_before = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def launch(self, videos_t_aug) -> MaskOut:
         from . import _lib
