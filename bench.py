@@ -13,9 +13,13 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernels (bf16 MFMA GEMM family + fused teacher kernel): algorithmic FLOPs / launch time,
                  measured with HIP events on the launch stream in a second pass of the same steps (events off during
                  the timed region so that `value` is undisturbed).  step_frac puts the whole step against the 2.5 PF/s
-                 bf16 peak (462.2 GF per clip); student_step_frac the student's part (179.7 GF per clip over
-                 student_ms = ms_per_step - teacher_ms, the number north_star's 40 % target is about); teacher_frac the
-                 frozen teacher (282.5 GF per clip over teacher_ms, its own steady-state loop).
+                 bf16 peak (462.2 GF per clip).  student_alone_ms / student_alone_frac: the student step (forward, decoders,
+                 loss, backward, grad-norm, AdamW: 179.7 GF per clip, the number north_star's 40 % target is about) MEASURED
+                 alone on the GPU in its own loop on pre-computed teacher outputs, planned for a GPU of its own;
+                 teacher_ms / teacher_frac: the frozen teacher alone (282.5 GF per clip).  step_minus_teacher_ms is the old
+                 subtraction (what the student ADDS to an overlapped step), kept under its own name.
+                 traffic: HBM bytes per launch from the PMC counters (profiles/, source quoted); traffic_algorithmic_bytes:
+                 the same launches' operands + outputs + residual / aux matrices, each once, per launch.
   host_enqueue_ms_per_step : wall time the host needs to enqueue one step (no sync inside a step).
   cpu_baseline : the CPU oracle (oracle/umt_oracle.py, fp32 torch) timed on this host's cores on a bounded sample.
 """
@@ -134,9 +138,9 @@ def main():
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     import unite_amd
-    from unite_amd import _lib
+    from unite_amd import _lib, ops
     from unite_amd.ddp import DistributedDataParallel
-    from unite_amd.engine_stage1 import StepState, TeacherAhead, stage1_step, student_phase
+    from unite_amd.engine_stage1 import StepState, TeacherAhead, stage1_step, student_phase, teacher_phase
     from unite_amd.optim_factory import create_optimizer
     from unite_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
     from types import SimpleNamespace
@@ -175,10 +179,11 @@ def main():
         graphed = GraphedStage1Step(model, teacher, opt, scaler, tuple(videos.shape), 0.8, clip_grad=None, state=state)
 
     ahead = TeacherAhead(teacher, state, dev, 0.8, 'attention') if (a.ahead == 1 and not a.serial and not use_graph) else None
-    if a.ahead == 1 and a.serial:
-        # --serial profiles the kernels of the default step one at a time: keep the planner setting that step runs with
-        _lib.load().unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
+    # the planner weight every GEMM launch of a step carries (unite_gemm_args.plan_sharing): the shared-GPU setting while the teacher runs
+    # ahead; --serial profiles the kernels of that default step one at a time and keeps its setting
+    share = [float(os.environ.get("UNITE_GEMM_SHARING", "0.8")) if (a.ahead == 1 and not use_graph) else 0.0]
     touts = []
+    torch.cuda.synchronize()               # `videos` is complete: the teacher's stream need not wait for the student's at every launch
 
     # experiment: extra HBM traffic on a stream of its own (UNITE_HBM_LOAD = GB copied per step) to see how memory-bound the step is
     hbm_gb = float(os.environ.get("UNITE_HBM_LOAD", "0"))
@@ -197,18 +202,19 @@ def main():
         it[0] += 1
         if graphed is not None and not graph_off[0]:
             return graphed(videos)
-        if ahead is not None and not graph_off[0]:
-            # every step enqueues ONE teacher phase (for the step after it) and ONE student step (on the outputs of the teacher phase
-            # enqueued a step earlier): K timed steps = K teacher forwards + K student steps, as in train_one_epoch
-            if not touts:
-                touts.append(ahead.launch(videos))
-            cur = touts.pop()
-            touts.append(ahead.launch(videos))
-            loss = student_phase(model, videos, cur, B, 'mixed')
-        else:
-            loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
-        opt.zero_grad()
-        gn = scaler(loss, opt, clip_grad=None, parameters=None, reducer=reducer)
+        with ops.plan(sharing=share[0]):
+            if ahead is not None and not graph_off[0]:
+                # every step enqueues ONE teacher phase (for the step after it) and ONE student step (on the outputs of the teacher phase
+                # enqueued a step earlier): K timed steps = K teacher forwards + K student steps, as in train_one_epoch
+                if not touts:
+                    touts.append(ahead.launch(videos, inputs_ready=False))
+                cur = touts.pop()
+                touts.append(ahead.launch(videos, inputs_ready=False))
+                loss = student_phase(model, videos, cur, B, 'mixed')
+            else:
+                loss = stage1_step(model, teacher, videos, B, 0.8, 'attention', None, 'mixed', state)
+            opt.zero_grad()
+            gn = scaler(loss, opt, clip_grad=None, parameters=None, reducer=reducer)
         return loss, gn
     graph_off = [False]
 
@@ -234,6 +240,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_v, gn_v = float(loss.item()), float(gn.item())
+    # random-init student against a random-init teacher: the cosine loss starts at ~2 and can only move inside [0, 4] (run_stage1.py:431)
+    if not (loss_v == loss_v and 0.0 <= loss_v <= 4.0 and gn_v == gn_v and gn_v > 0.0):
+        raise SystemExit(f"bench: implausible final loss {loss_v} / grad-norm {gn_v}: the timed steps did not train")
     ms_step = dt / a.steps * 1e3
     if rank == 0:
         print(f"[bench] timed region: {a.steps} steps in {dt:.3f} s ({dt / a.steps * 1e3:.2f} ms/step), loss {loss_v:.4f}", file=sys.stderr, flush=True)
@@ -245,30 +254,46 @@ def main():
         teacher.runtime().two_streams = on
         state.overlap_targets = on
 
-    # the step by phase (as tools/phase_time.py): the frozen teacher ALONE on the GPU in a steady-state loop, configured as in the timed region;
-    # student = step - teacher (student forward / backward / AdamW).  With the teacher one batch ahead the two phases overlap in the timed
-    # region, so this difference is what the student adds to a step, not the time its kernels would take alone.
-    teacher_ms = None
+    # the step by phase: the frozen teacher ALONE on the GPU in a steady-state loop (configured as in the timed region), and the student step
+    # ALONE on the GPU (forward, decoders, loss, backward with its side-stream weight gradients, grad-norm, AdamW) on the outputs of ONE
+    # pre-computed teacher phase, every launch planned for a GPU of its own (sharing 0) -- a measurement, not step - teacher
+    teacher_ms, student_alone_ms = None, None
     if not a.no_roofline:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_t = min(a.steps, 20)
-        trt, lib_ = teacher.runtime(), _lib.load()
-        keep_streams, keep_policy = trt.n_streams, lib_.unite_gemm_get_policy()
-        if ahead is not None:           # the teacher as the timed region runs it: one stream, tile GEMM kernels
+        trt = teacher.runtime()
+        keep_streams = trt.n_streams
+        if ahead is not None:           # the teacher as the timed region runs it: one stream, tile GEMM kernels, shared-GPU planner weight
             trt.n_streams = ahead.n_streams
-            if ahead.gemm_policy >= 0:
-                lib_.unite_gemm_set_policy(ahead.gemm_policy)
-        for _ in range(3):
-            teacher.forward_attention(videos)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(n_t):
-            teacher.forward_attention(videos)
-        ev1.record()
-        torch.cuda.synchronize()
+        with (ahead.hints() if ahead is not None else ops.plan(sharing=share[0])):
+            for _ in range(3):
+                teacher.forward_attention(videos)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(n_t):
+                teacher.forward_attention(videos)
+            ev1.record()
+            torch.cuda.synchronize()
         teacher_ms = ev0.elapsed_time(ev1) / n_t
         trt.n_streams = keep_streams
-        lib_.unite_gemm_set_policy(keep_policy)
+        if world == 1 and graphed is None:
+            with ops.plan(sharing=0.0):
+                tout_fixed = teacher_phase(teacher, videos, 0.8, 'attention', None, state, slot=7, inline_targets=True)
+                torch.cuda.synchronize()
+
+                def student_step():
+                    l_ = student_phase(model, videos, tout_fixed, B, 'mixed')
+                    opt.zero_grad()
+                    scaler(l_, opt, clip_grad=None, parameters=None, reducer=reducer)
+                for _ in range(3):
+                    student_step()
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(n_t):
+                    student_step()
+                ev1.record()
+                torch.cuda.synchronize()
+            student_alone_ms = ev0.elapsed_time(ev1) / n_t
 
     roof = None
     if not a.no_roofline:
@@ -282,17 +307,16 @@ def main():
         for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
-        ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
-        lib.unite_prof_summary(C.byref(ms), C.byref(cnt), C.byref(fl))
+        ms, cnt, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        lib.unite_prof_summary(C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by))
         lib.unite_prof_enable(0, 0)
         print(f"[bench] profiled pass: {cnt.value} MFMA-kernel launches, {ms.value:.1f} ms", file=sys.stderr, flush=True)
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         # the same pass with every launch planned for a GPU of its own (sharing weight 0): what the kernels reach when they are both
         # configured and measured stand-alone
         ach_alone = None
-        share = lib.unite_gemm_get_sharing()
-        if share > 0:
-            lib.unite_gemm_set_sharing(0.0)
+        if share[0] > 0:
+            keep_share, share[0] = share[0], 0.0
             step()
             lib.unite_prof_enable(1, 400 * n_prof)
             torch.cuda.synchronize()
@@ -300,40 +324,44 @@ def main():
                 step()
             torch.cuda.synchronize()
             ms2, cnt2, fl2 = C.c_double(), C.c_int64(), C.c_double()
-            lib.unite_prof_summary(C.byref(ms2), C.byref(cnt2), C.byref(fl2))
+            lib.unite_prof_summary(C.byref(ms2), C.byref(cnt2), C.byref(fl2), None)
             lib.unite_prof_enable(0, 0)
-            lib.unite_gemm_set_sharing(share)
+            share[0] = keep_share
             ach_alone = fl2.value / (ms2.value * 1e-3) / 1e12 if ms2.value > 0 else None
         # HBM bytes per MFMA-kernel launch: NOT measured by this run (PMC counters need rocprofv3: tools/final_prof.sh collects the
         # FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` and tools/pmc_traffic.py reduces them); quoted with its source, or null
         traffic, traffic_source = None, None
-        for name in ("r02_gemm_traffic.json",):
+        for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tp):
                 tj = json.load(open(tp))
                 traffic = round(tj["traffic_bytes_per_launch"])
                 traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of bench.py --serial at commit {tj.get('commit', '?')}; not measured in this run)"
+                break
         roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM kernels: gemm_deep_kernel / gemm_wide_kernel family (all layouts/epilogues) + teacher_qkv_attn_kernel (projection + attention FLOPs)", "achieved": round(ach, 1),
                 "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                 "traffic_source": traffic_source,
+                "traffic_algorithmic_bytes": round(by.value / max(cnt.value, 1)),
                 "frac_planned_alone": None if ach_alone is None else round(ach_alone * 1e12 / PEAK_BF16, 4),
                 "launches_per_step": cnt.value // n_prof, "gemm_ms_per_step": round(ms.value / n_prof, 3),
                 "gemm_gflop_per_step": round(fl.value / n_prof / 1e9, 1),
                 "step_mfma_frac_full": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
                 "step_frac": round(clips_s / world * (GF_STUDENT + GF_TEACHER) / PEAK_BF16, 4),
-                "teacher_ms": round(teacher_ms, 3), "student_ms": round(ms_step - teacher_ms, 3),
-                "student_step_frac": round(B * GF_STUDENT / ((ms_step - teacher_ms) * 1e-3) / PEAK_BF16, 4),
+                "teacher_ms": round(teacher_ms, 3),
                 "teacher_frac": round(B * GF_TEACHER / (teacher_ms * 1e-3) / PEAK_BF16, 4),
+                "student_alone_ms": None if student_alone_ms is None else round(student_alone_ms, 3),
+                "student_alone_frac": None if student_alone_ms is None else round(B * GF_STUDENT / (student_alone_ms * 1e-3) / PEAK_BF16, 4),
+                "step_minus_teacher_ms": round(ms_step - teacher_ms, 3),
                 "note": "HIP events on the launch stream around every launch of these kernels in a second pass of the same steps, run on ONE stream "
                         "(the timed region overlaps the teacher of the next batch, the student and its weight-gradient GEMMs on separate streams, "
                         "which would charge each launch for time it shares with other kernels); same kernels and planner setting as the timed "
                         "region, same numbers as `bench.py --serial` under rocprofv3.  The planner sizes launches for a SHARED GPU "
-                        "(unite_gemm_set_sharing 0.8: larger tiles, fewer split-K slices), so these stand-alone durations are longer "
+                        "(plan_sharing 0.8 in every unite_gemm_args: larger tiles, fewer split-K slices), so these stand-alone durations are longer "
                         "than with UNITE_GEMM_SHARING=0 (frac_planned_alone: the same pass planned and measured stand-alone) while the step is shorter: step_frac is the number that counts the whole step"}
     elif world > 1:
         # keep ranks in lock-step with rank 0's profiled passes (every step all-reduces)
         n_prof = min(a.steps, 5)
-        for _ in range(n_prof + ((1 + n_prof) if _lib.load().unite_gemm_get_sharing() > 0 else 0)):
+        for _ in range(n_prof + ((1 + n_prof) if share[0] > 0 else 0)):
             step()
         torch.cuda.synchronize()
 
@@ -350,7 +378,8 @@ def main():
             if k == 3:
                 torch.cuda.synchronize()
                 th = time.perf_counter()
-            l2 = stage1_step(model, teacher, v2, 2, 0.8, 'attention', None, 'mixed', st2)
+            with ops.plan(sharing=share[0]):
+                l2 = stage1_step(model, teacher, v2, 2, 0.8, 'attention', None, 'mixed', st2)
             opt.zero_grad()
             scaler(l2, opt, clip_grad=None, parameters=None, reducer=reducer)
         torch.cuda.synchronize()

@@ -29,7 +29,7 @@ extern "C" {
 #define UNITE_EINVAL (-1)     /* bad shape / alignment / null pointer */
 #define UNITE_ENOSUP (-2)     /* shape outside what the kernels were built for */
 
-#define UNITE_ABI_VERSION 1
+#define UNITE_ABI_VERSION 2
 int unite_abi_version(void);
 /* name of the code-object target the library was built for ("gfx950") */
 const char* unite_target_arch(void);
@@ -48,7 +48,7 @@ const char* unite_target_arch(void);
  *   act == UNITE_ACT_QUICKGELU : v = v * sigmoid(1.702 v)                       (clip.py:29-31)
  *   act == UNITE_ACT_DGELU     : v *= gelu_erf'(aux_in[m,n])                    (backward of fc1)
  *   v *= row_scale[m / rows_per_scale]             (row_scale != NULL; stochastic depth)
- *   v += residual[m,n]                             (residual != NULL, f32, ld = ldr)
+ *   v += residual[m,n]                             (residual != NULL; f32, or bf16 if residual_bf16 != 0; ld = ldr)
  *   v += out[m,n]                                  (accumulate != 0, f32 out only)
  *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given;  colsum_out (+)= column sums of out.
  * ------------------------------------------------------------------------------------ */
@@ -64,19 +64,37 @@ typedef struct unite_gemm_args {
     const void* aux_in;  int32_t ld_aux_in;     /* bf16 [M,N] */
     void* aux_out;       int32_t ld_aux_out;    /* bf16 [M,N] */
     const float* row_scale; int32_t rows_per_scale;
-    const float* residual;  int32_t ldr;
+    const void* residual;   int32_t ldr;        /* f32 [M,N] (bf16 [M,N] if residual_bf16 != 0, see below) */
     void* out; int32_t ldc; int32_t out_f32; int32_t accumulate;
     void* out_bf16_copy; int32_t ld_copy;
     void* workspace; int64_t workspace_bytes;   /* optional scratch (16-byte aligned): lets short-and-wide products with a plain
                                                    f32 output (weight gradients) run split-K through f32 slabs [S][M][N],
-                                                   summed in a fixed order (bitwise reproducible); NULL = never split */
+                                                   summed in a fixed order (bitwise reproducible) by the LAST slice of a tile to
+                                                   finish, inside the same launch; NULL = never split.  Layout: a header of
+                                                   UNITE_WS_HEADER_BYTES (arrival counters) that must be ZERO before the first
+                                                   call and is left zero by every call, then the slabs.  One workspace per
+                                                   stream: two launches in flight must not share one. */
     float* colsum_out; int32_t colsum_accumulate;
                                                 /* optional f32 [N]: colsum_out[n] (+)= sum over m of the STORED out[m,n] (after rounding
                                                    for a bf16 output) -- the bias gradient of the Linear whose input gradient this
                                                    product is (db = colsum(dY), modeling_finetune.py:67 under autograd), so that dY is
                                                    not read again for it.  Per-tile partial sums go through `workspace`
                                                    (>= unite_gemm_colsum_workspace(M, N) bytes), summed in a fixed order. */
+    /* ---- ABI 2: everything below may be left zero (a zeroed struct asks for the process-wide defaults) ---- */
+    int32_t plan_flags;                         /* bit 0: plan_persistent is a per-call hint, bit 1: plan_sharing is */
+    int32_t plan_persistent;                    /* as unite_gemm_set_policy, for THIS launch only */
+    float   plan_sharing;                       /* as unite_gemm_set_sharing, for THIS launch only */
+    int32_t residual_bf16;                      /* `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream) */
+    float* rowsum_a_out;                        /* optional f32 [M]: rowsum_a_out[m] (+)= sum_k op(A)[m,k] -- for a weight gradient
+                                                   dW = dY^T X (trans_a = 1, A = dY stored [tokens, out]) this is the bias gradient
+                                                   db = colsum(dY) (modeling_finetune.py:67,106 under autograd), taken from the A tiles
+                                                   the product already holds in LDS.  Deep tile kernels only; with split-K the
+                                                   per-slice partial sums go through `workspace` like the slabs (fixed order). */
+    int32_t rowsum_accumulate;
+    int32_t rowsum_zero_lo, rowsum_zero_hi;     /* rows in [lo, hi) are written as 0 instead (the k third of the packed (q,0,v) bias) */
 } unite_gemm_args;
+
+#define UNITE_WS_HEADER_BYTES 32768             /* 4096 tile counters + 4096 spare words */
 
 size_t unite_gemm_colsum_workspace(int32_t M, int32_t N);
 
@@ -87,6 +105,8 @@ int unite_gemm_bf16(const unite_gemm_args* args, void* stream);
  * K % 64 == 0, K >= 768) instead of the tile kernels.  0 never, 1 the shapes it measured faster on (default), 2 whenever it
  * supports the problem, -1 back to the UNITE_GEMM_PP environment variable.  Results are the same either way (f32 accumulation
  * in K order inside a K-tile; integer-valued products are bit-exact on both). */
+/* The setters below change PROCESS-WIDE DEFAULTS only; a caller that needs a different choice for some launches passes it in
+ * unite_gemm_args.plan_* (no global is written on that path, so host threads do not see each other's hints). */
 int unite_gemm_set_policy(int32_t persistent);
 /* the value last set (-1 if the environment variable decides): lets a caller change the policy for a group of launches and put it back */
 int unite_gemm_get_policy(void);
@@ -109,9 +129,10 @@ int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t count, void* st
 /* Diagnostics for bench.py's roofline leg: when enabled, every unite_gemm_bf16 launch is bracketed by two HIP events
  * recorded on the launch stream (pool of max_launches pairs; launches beyond the pool are not timed).
  * unite_prof_summary synchronises on the recorded events and returns the summed durations (ms), the number of timed
- * launches and their algorithmic FLOPs (2 M N K each).  Not for use under stream capture. */
+ * launches, their algorithmic FLOPs (2 M N K each) and their algorithmic HBM bytes (every operand, output, residual and saved
+ * pre-activation matrix once).  Not for use under stream capture. */
 int unite_prof_enable(int32_t on, int32_t max_launches);
-int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops);
+int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (D % 4 == 0, D <= 1024), one wavefront per row, fp32 statistics.
@@ -125,6 +146,11 @@ int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index,
                         void* y, int32_t y_f32,           /* [M,D] bf16 or f32 */
                         float* mean, float* rstd,         /* [M] or NULL */
                         int32_t M, int32_t D, void* stream);
+/* The same with a bf16 input matrix (x: bf16 [*, ldx]): the frozen teacher's residual stream when it is kept in bf16
+ * (clip.py:60-64 under no_grad; unite_amd.clip UNITE_TEACHER_RES16). */
+int unite_layernorm_fwd_bf16in(const void* x, int32_t ldx, const int32_t* row_index,
+                               const float* gamma, const float* beta, float eps, const float* post_add,
+                               void* y, int32_t y_f32, float* mean, float* rstd, int32_t M, int32_t D, void* stream);
 
 /* Backward of y = LN(x)*gamma+beta.  dy is bf16 (dy_f32 == 0) or f32 [M,D].
  *   dx_out[i,:] = (dx_residual ? dx_residual[i,:] : 0) + dLN/dx
@@ -142,7 +168,9 @@ int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* x, int32_t 
                         void* workspace, int32_t M, int32_t D, void* stream);
 
 /* Column sums of a bf16 matrix (bias gradients): out[n] (+)= sum_m x[m,n]; columns in [zero_lo, zero_hi) are written
- * as 0 instead (the k third of the packed (q,0,v) attention bias).  workspace >= unite_colsum_workspace(M, N) bytes. */
+ * as 0 instead (the k third of the packed (q,0,v) attention bias).  workspace >= unite_colsum_workspace(M, N) bytes; ONE launch:
+ * the row block of a 512-column block that finishes last adds the partial rows in order.  The first 4096 bytes of the workspace are
+ * arrival counters: ZERO before the first call, left zero by every call. */
 size_t unite_colsum_workspace(int32_t M, int32_t N);
 int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
                       int32_t zero_lo, int32_t zero_hi, void* workspace, void* stream);
@@ -213,9 +241,9 @@ int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modu
 int unite_gather_rows_bf16(const void* table, const int32_t* index, void* out, int32_t n_rows, int32_t D, void* stream);
 
 /* CLIP token assembly + ln_pre (clip.py:148-152): patches bf16 [BT*HW, D] ->
- * x f32 [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding). */
+ * x [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding), f32 (x_f32 != 0) or bf16. */
 int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,
-                        const float* gamma, const float* beta, float eps, float* x,
+                        const float* gamma, const float* beta, float eps, void* x, int32_t x_f32,
                         int32_t BT, int32_t HW, int32_t D, void* stream);
 
 /* rows /= ||row||_2  (f32 [M,D], in place; clip.py:172-173). */

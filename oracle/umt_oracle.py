@@ -594,8 +594,13 @@ def clip_infer(sd: SD, videos: Tensor, text_features: Tensor, cfg: TeacherCfg) -
     """src/utils.py:55-68: per-frame similarities (x100, soft-max over classes) averaged over the frames of each clip."""
     B, C, T, H, Wd = videos.shape
     images = videos.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, Wd)
-    f = clip_encode_image(sd, images, cfg)
-    f = f / f.norm(dim=-1, keepdim=True)
+    return clip_similarity(clip_encode_image(sd, images, cfg), text_features, B)
+
+
+def clip_similarity(image_features: Tensor, text_features: Tensor, B: int) -> Tensor:
+    """src/utils.py:61-68, the arithmetic behind encode_image: normalise both sides, softmax(100 cos) per frame, mean over a clip's frames.
+    image_features (B*T, C), text_features (n_cls, C) -> (B, n_cls).  Pinned on the reference's own clip_infer (tests/golden/stage3_step.npz)."""
+    f = image_features / image_features.norm(dim=-1, keepdim=True)
     t = text_features / text_features.norm(dim=-1, keepdim=True)
     sim = (100 * f @ t.t()).softmax(dim=-1)
-    return sim.view(B, T, -1).mean(dim=1)
+    return sim.view(B, -1, sim.shape[-1]).mean(dim=1)

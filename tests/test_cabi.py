@@ -30,10 +30,22 @@ def test_ctypes_table_matches_header():
     from unite_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.unite_abi_version() == 1
+    assert lib.unite_abi_version() == 2
     assert lib.unite_target_arch() == b"gfx950"
-    # struct layout: the header's unite_gemm_args has 10 pointer-or-int64 and 17 int32 fields
-    assert ctypes.sizeof(_lib.GemmArgs) % 8 == 0 and len(_lib.GemmArgs._fields_) == 29
+    # struct layout: the ctypes mirror lists the fields of the header's unite_gemm_args, in order, with matching kinds
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "unite_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct unite_gemm_args \{(.*?)\} unite_gemm_args;", text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        kind = "ptr" if "*" in decl else ("i64" if "int64_t" in decl else ("f32" if decl.startswith("float") else "i32"))
+        for name in re.sub(r"^[a-z0-9_ ]*?\b(?=[A-Za-z_]+\s*(,|$))", "", decl.replace("*", " ")).split(","):
+            fields.append((name.strip().split()[-1], kind))
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int32: "i32", ctypes.c_int64: "i64", ctypes.c_float: "f32"}
+    assert [(n, kinds[t]) for n, t in _lib.GemmArgs._fields_] == fields
+    assert ctypes.sizeof(_lib.GemmArgs) % 8 == 0 and len(fields) == 37
 
 
 def test_comm_header_symbols_are_exported():
@@ -56,7 +68,7 @@ def test_workspace_queries_run_without_gpu():
     assert ops.layernorm_bwd_workspace(10240, 768) == (10240 // 16) * 3 * 768 * 4
     assert ops.colsum_workspace(1000, 776) > 0
     assert ops.grad_norm_workspace(88_005_888) > 0
-    assert ops.gemm_colsum_workspace(10240, 3072) == 80 * 3072 * 4          # one partial row per 128 output rows
+    assert ops.gemm_colsum_workspace(10240, 3072) == 32768 + 80 * 3072 * 4          # counters header + one partial row per 128 output rows
 
 
 def test_no_cpu_fallback():

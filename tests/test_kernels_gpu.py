@@ -112,6 +112,96 @@ def test_gemm_splitk_weight_gradient(ops, M, N, K):
     torch.testing.assert_close(o1.cpu(), bf(x).float().t() @ bf(y).float(), atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,ws_on", [(768, 768, 10240, True), (3072, 768, 10240, True), (2304, 768, 10240, True), (136, 264, 1100, True),
+                                          (520, 136, 328, False), (256, 128, 64, False)])
+def test_gemm_rowsum_of_a_beside_the_weight_gradient(ops, M, N, K, ws_on):
+    """rowsum_out of unite_gemm_bf16 on a TN product (dW = dY^T X): the bias gradient colsum(dY), taken from the A tiles the product holds
+    in LDS (MFMA against a one-hot B fragment), with and without split-K (in-launch reduction of the per-slice sums).  Integer data: exact.
+    The product itself is unchanged; rows in rowsum_zero_range are written as zeros; accumulate adds; two calls agree bit for bit."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(-3, 4, (K, M), generator=g).float()
+    b = torch.randint(-3, 4, (K, N), generator=g).float()
+    ref = (a.double().t() @ b.double()).float()
+    rs_ref = a.double().sum(0).float()
+    ws = torch.empty(96 << 20, dtype=torch.uint8, device=DEV) if ws_on else None
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    rs = torch.full((M,), float("nan"), device=DEV)
+    ad, bd = bf(a).to(DEV), bf(b).to(DEV)
+    ops.gemm(ad, bd, out, trans_a=True, trans_b=True, workspace=ws, rowsum_out=rs)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(rs.cpu(), rs_ref)
+    lo, hi = M // 3 // 8 * 8, 2 * (M // 3 // 8 * 8)
+    rs2 = rs.clone()
+    ops.gemm(ad, bd, out, trans_a=True, trans_b=True, workspace=ws, rowsum_out=rs2, rowsum_accumulate=True, rowsum_zero_range=(lo, hi))
+    exp = 2 * rs_ref
+    exp[lo:hi] = rs_ref[lo:hi]                     # the zeroed rows contribute 0 to the accumulation (as unite_colsum_bf16's zero range)
+    assert torch.equal(rs2.cpu(), exp)
+    rs3 = torch.full((M,), float("nan"), device=DEV)
+    ops.gemm(ad, bd, out, trans_a=True, trans_b=True, workspace=ws, rowsum_out=rs3, rowsum_zero_range=(lo, hi))
+    exp = rs_ref.clone()
+    exp[lo:hi] = 0
+    assert torch.equal(rs3.cpu(), exp)
+    x = torch.randn(K, M, generator=g)
+    xd, yd = bf(x).to(DEV), bf(torch.randn(K, N, generator=g)).to(DEV)
+    r1, r2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    o1, o2 = torch.empty_like(out), torch.empty_like(out)
+    ops.gemm(xd, yd, o1, trans_a=True, trans_b=True, workspace=ws, rowsum_out=r1)
+    ops.gemm(xd, yd, o2, trans_a=True, trans_b=True, workspace=ws, rowsum_out=r2)
+    assert torch.equal(r1, r2) and torch.equal(o1, o2)
+    torch.testing.assert_close(r1.cpu().double(), bf(x).double().sum(0), atol=2e-3 * K ** 0.5, rtol=1e-5)
+
+
+def test_gemm_rowsum_of_a_k_contiguous(ops):
+    """the same for A stored [M, K] (trans_a = 0): row sums of A itself"""
+    M, N, K = 392, 264, 200
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    rs = torch.empty(M, device=DEV)
+    ops.gemm(bf(a).to(DEV), bf(b).to(DEV), out, rowsum_out=rs)
+    assert torch.equal(out.cpu(), a @ b.t())
+    assert torch.equal(rs.cpu(), a.sum(1))
+
+
+@pytest.mark.parametrize("policy", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(330, 264, 192), (1970, 768, 768), (2048, 768, 3072)])
+def test_gemm_bf16_residual_stream(ops, M, N, K, policy):
+    """bf16 output + bf16 residual (unite_gemm_args.residual_bf16: the frozen teacher's bf16 residual stream), on the tile kernels and on
+    the persistent kernel: out = bf16(acc + bias + residual), the sum taken in f32."""
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3), bf(rnd(M, N, seed=4))
+    ref = a.float() @ w.float().t() + bias + res.float()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    with ops.plan(persistent=policy):
+        ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=res.to(DEV))
+    torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=1e-2)
+    # exact on integers: the rounding to bf16 is the only inexact step, and small integers survive it
+    g = torch.Generator().manual_seed(9)
+    ai = torch.randint(-2, 3, (M, K), generator=g).float()
+    wi = torch.randint(-2, 3, (N, K), generator=g).float()
+    ri = torch.randint(-8, 9, (M, N), generator=g).float()
+    # K <= 3072 products of magnitude <= 4: |acc| < 2^14; bf16 holds integers exactly up to 256 -> compare what bf16 rounding gives
+    with ops.plan(persistent=policy):
+        ops.gemm(bf(ai).to(DEV), bf(wi).to(DEV), out, residual=bf(ri).to(DEV))
+    assert torch.equal(out.cpu(), bf(ai @ wi.t() + ri))
+
+
+def test_layernorm_fwd_bf16_input(ops):
+    """unite_layernorm_fwd_bf16in: LayerNorm of bf16 rows (the teacher's bf16 residual stream), statistics in f32, with a row index"""
+    M, D = 197 * 3, 768
+    x = bf(rnd(M, D, seed=1, scale=3.0))
+    gam, bet = rnd(D, seed=2) * 0.1 + 1, rnd(D, seed=3) * 0.1
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gam, bet, 1e-5)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y)
+    torch.testing.assert_close(y.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    idx = torch.tensor([5, 0, 400, 588, 17], dtype=torch.int32)
+    y2 = torch.empty(5, D, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y2, row_index=idx.to(DEV))
+    torch.testing.assert_close(y2.cpu(), ref[idx.long()], atol=1e-5, rtol=1e-5)
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 330, 264, 192
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))

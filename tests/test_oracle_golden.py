@@ -181,3 +181,41 @@ def test_stage1_curve_first_steps(golden_dir):
                 # no-decay group: 1-D tensors, .bias, and no_weight_decay() names (optim_factory.py:76-118)
                 O.adamw_step(p, p.grad, m[k], v[k], it + 1, float(lr[it]), b1, b2, float(z["opt.eps"]), float(z["opt.wd"]) if p.ndim > 1 else 0.0)
                 p.grad = None
+
+
+def test_stage3_step_vs_reference_golden(golden_dir):
+    """oracle.stage3_loss / stage3_pseudo_labels / clip_similarity against the reference's OWN stage-3 train_one_epoch (run_stage3.py:340-710,
+    executed from its syntax tree by oracle/make_golden_stage3.py: tests/golden/stage3_step.npz) for all seven selection strategies: the
+    classifier logits of the three student passes, the committee masks, the zero-shot similarities, source / target / total loss, the
+    select ratio, every per-tensor gradient norm and eight gradient tensors."""
+    z = _load(golden_dir, "stage3_step.npz")
+    ssd0 = fill_state_dict(student_shapes(TINY_S), int(z["in.seed_student"]))
+    tsd = fill_state_dict(teacher_shapes(TINY_T), int(z["in.seed_teacher"]))
+    t = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("in.") and v.dtype.kind in "fi" and v.ndim > 0}
+    B_t = t["videos_t"].shape[0]
+    sims = O.clip_similarity(t["img_feats"], t["text_feats"], B_t)
+    _, attn = O.teacher_forward(tsd, t["videos_t_aug"], TINY_T, return_attn=True)
+    masks = O.get_greedy_masks(attn, float(z["in.mask_ratio"]), 2)
+    for strat in [str(s) for s in z["in.strategies"]]:
+        pre = strat + "."
+        assert np.array_equal(masks.numpy(), z[pre + "masks"])
+        if pre + "similarities" in z:
+            np.testing.assert_allclose(sims.numpy(), z[pre + "similarities"], atol=2e-6, rtol=0)
+        ssd = {k: v.clone().requires_grad_(True) for k, v in ssd0.items()}
+        loss, loss_s, loss_t, sel = O.stage3_loss(ssd, tsd, t["cls_w"], t["cls_b"], t["videos_s"], t["labels_s"], t["videos_t"], t["videos_t_aug"],
+                                                  t["labels_t"], TINY_S, TINY_T, float(z["in.mask_ratio"]), strat, clip_probs_t=sims,
+                                                  clip_threshold=float(z["in.clip_threshold"]))
+        np.testing.assert_allclose(float(loss_s), z[pre + "loss_s"], atol=TOL, rtol=0, err_msg=strat)
+        np.testing.assert_allclose(float(loss_t), z[pre + "loss_t"], atol=TOL, rtol=0, err_msg=strat)
+        np.testing.assert_allclose(float(loss), z[pre + "loss"], atol=TOL, rtol=0, err_msg=strat)
+        assert float(sel.float().mean()) == float(z[pre + "select_ratio"]), strat
+        loss.backward()
+        gn = O.grad_norm([p.grad for k, p in ssd.items() if p.grad is not None])
+        np.testing.assert_allclose(float(gn), z[pre + "grad_norm"], rtol=2e-5, err_msg=strat)
+        for k, p in ssd.items():
+            if k.startswith("clip_decoder."):
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0          # run_stage3.py:475 discards the decoder outputs
+                continue
+            np.testing.assert_allclose(float(p.grad.norm()), z[pre + "gnorm." + k], rtol=1e-4, atol=1e-6, err_msg=k)
+            if pre + "g." + k in z:
+                np.testing.assert_allclose(p.grad.numpy(), z[pre + "g." + k], atol=5e-5, rtol=1e-4, err_msg=k)

@@ -4,7 +4,8 @@
     python tools/bench_configs.py vitl   [--batch 8]
     python tools/bench_configs.py stage2 [--batch 16]
 FLOP counts are SURVEY.md 8(d)'s algorithmic figures; kernel time split via UNITE profiling (unite_prof_*)."""
-import argparse, json, os, sys, time
+import argparse
+import contextlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from types import SimpleNamespace
@@ -85,12 +86,13 @@ elif a.config == "stage3":
         m = None
         if ahead is not None:          # the default schedule of engine_stage3.train_one_epoch: mask teacher of the next batch beside this step
             if not mouts:
-                mouts.append(ahead.launch(va))
+                mouts.append(ahead.launch(va, inputs_ready=False))
             m = mouts.pop()
-            mouts.append(ahead.launch(va))
-        loss, *_ = stage3_step(student, teacher, cls, vs, ls, vt, va, lt, args, 0.8, clip_probs_fn=lambda v: probs, clip_input_resolution=res, masks=m)
-        opt.zero_grad()
-        return loss, scaler(loss, opt, clip_grad=None)
+            mouts.append(ahead.launch(va, inputs_ready=False))
+        with (ahead.student() if ahead is not None else contextlib.nullcontext()):
+            loss, *_ = stage3_step(student, teacher, cls, vs, ls, vt, va, lt, args, 0.8, clip_probs_fn=lambda v: probs, clip_input_resolution=res, masks=m)
+            opt.zero_grad()
+            return loss, scaler(loss, opt, clip_grad=None)
     name, units = f"stage3 ViT-B/16 student + {a.teacher} mask teacher, 8fx224^2, B={B} src + {B} tgt (zero-shot CLIP probabilities injected)", B
 else:
     from unite_amd.engine_stage1 import stage1_step, StepState
@@ -117,16 +119,19 @@ else:
     def step():
         if ahead is not None:      # the default schedule of train_one_epoch: teacher of the next batch beside the student of this one
             if not touts:
-                touts.append(ahead.launch(vid))
+                touts.append(ahead.launch(vid, inputs_ready=False))
             cur = touts.pop()
-            touts.append(ahead.launch(vid))
-            loss = student_phase(student, vid, cur, B, 'mixed')
-        else:
-            loss = stage1_step(student, teacher, vid, B, 0.8, 'attention', None, 'mixed', st, clip_input_resolution=196)
+            touts.append(ahead.launch(vid, inputs_ready=False))
+            with ahead.student():
+                loss = student_phase(student, vid, cur, B, 'mixed')
+                opt.zero_grad()
+                return loss, scaler(loss, opt, clip_grad=None)
+        loss = stage1_step(student, teacher, vid, B, 0.8, 'attention', None, 'mixed', st, clip_input_resolution=196)
         opt.zero_grad()
         return loss, scaler(loss, opt, clip_grad=None)
     name, units = "stage1 ViT-L/16 student (16fx224^2, 640 visible tokens) + CLIP-L/14 teacher @196", B
 
+torch.cuda.synchronize()          # the synthetic clips are complete before the first teacher launch reads them on its own stream
 for _ in range(a.warmup):
     loss, gn = step()
 torch.cuda.synchronize()

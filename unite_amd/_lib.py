@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libunite_hip.so")
 LIB_PATH = os.environ.get("UNITE_HIP_LIB", LIB_PATH)        # A/B runs of two builds of the library in one gpurun call
 
+ABI_VERSION = 2               # UNITE_ABI_VERSION of include/unite_hip.h
+WS_HEADER_BYTES = 32768       # UNITE_WS_HEADER_BYTES: arrival counters at the head of a GEMM workspace (zero outside a launch)
+
 c_p = C.c_void_p
 c_i = C.c_int32
 c_f = C.c_float
@@ -39,6 +42,10 @@ class GemmArgs(C.Structure):
         ("out_bf16_copy", c_p), ("ld_copy", c_i),
         ("workspace", c_p), ("workspace_bytes", c_i64),
         ("colsum_out", c_p), ("colsum_accumulate", c_i),
+        # ABI 2 (zero = process-wide defaults / feature off)
+        ("plan_flags", c_i), ("plan_persistent", c_i), ("plan_sharing", c_f),
+        ("residual_bf16", c_i),
+        ("rowsum_a_out", c_p), ("rowsum_accumulate", c_i), ("rowsum_zero_lo", c_i), ("rowsum_zero_hi", c_i),
     ]
 
 
@@ -54,8 +61,9 @@ SIGNATURES = {
     "unite_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "unite_gemm_bf16_grouped": (c_i, [C.POINTER(GemmArgs), c_i, c_p]),
     "unite_prof_enable": (c_i, [c_i, c_i]),
-    "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
+    "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "unite_layernorm_fwd_bf16in": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_colsum_workspace": (c_sz, [c_i, c_i]),
@@ -70,7 +78,7 @@ SIGNATURES = {
     "unite_im2col_gather": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "unite_gather_rows_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     "unite_gather_rows_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
-    "unite_clip_embed_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "unite_clip_embed_ln": (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_l2_normalize_rows": (c_i, [c_p, c_i, c_i, c_p]),
     "unite_mask_sample": (c_i, [c_p, c_u64, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "unite_drop_path_scales": (c_i, [c_p, c_u64, c_p, c_i, c_i, c_p]),
@@ -118,7 +126,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.unite_abi_version() != 1:
+    if lib.unite_abi_version() != ABI_VERSION:
         raise UniteHipError("libunite_hip.so ABI version mismatch")
     _lib = lib
     return lib

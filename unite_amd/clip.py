@@ -164,8 +164,36 @@ class _TeacherRuntime:
         self._rows_cache = {}
         self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_STREAMS", "3")))
         self.fused_qkv = os.environ.get("UNITE_TEACHER_FUSED", "1") != "0" and 192 < self.L <= 224
+        # Residual stream of the FROZEN teacher in bf16 (round 3, OPT-IN: UNITE_TEACHER_RES16=1): x, x1 and the taps are written and re-read as
+        # bf16 rows, which takes 464 MB per block off the HBM traffic of the two residual GEMMs and the two LayerNorms (2.0 -> 1.55 GB per
+        # block at B = 32).  The sums themselves stay f32 (accumulator + residual are added in f32 in the GEMM epilogue, rounded once on the
+        # store; LayerNorm statistics in f32), but each block then adds two bf16 roundings of the whole stream: measured on the tiny golden
+        # teacher the CLS attention moves by up to 1e-2 absolute (4 % relative: bf16 GEMM operands alone give 1 %), OUTSIDE the 2e-3 / 2 % bound
+        # of test_teacher_tiny_vs_reference_golden, while the L2-normalised targets keep cosine > 0.9999.  The reference's own GPU path
+        # (fp16 autocast) keeps an f32 stream, so the default stays f32; the switch exists for A/B measurements.
+        self.res16 = os.environ.get("UNITE_TEACHER_RES16", "0") != "0"
         self.min_frames_per_stream = 64
         self._side = []
+        # the flat parameter buffer and its bf16 shadow were just built on the CURRENT stream: the first forward may come from another one
+        # (TeacherAhead / MaskTeacherAhead call runtime() on the student's stream and run the teacher on their own), so the construction
+        # counts as the first "use" the next one is ordered behind.  (Round 3: found as masks / targets of the first batch computed from
+        # half-copied weights whenever the student's stream was busy at that moment.)
+        self._use_ev, self._use_stream = None, None
+        self._leave(torch.cuda.current_stream())
+
+    # The workspace (x / h / qkv / o / a / taps) and the tap bookkeeping belong to ONE forward at a time.  Two callers on different
+    # streams -- stage 3's mask teacher one batch ahead on its own stream and utils.clip_infer(teacher_model, ...) on the student's stream
+    # -- are put in order here: a use starts behind the end of the previous use whenever that one ran on another stream.
+    def _enter(self):
+        cur = torch.cuda.current_stream()
+        if self._use_ev is not None and self._use_stream != cur:
+            cur.wait_event(self._use_ev)
+        return cur
+
+    def _leave(self, cur):
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._use_ev, self._use_stream = ev, cur
 
     @property
     def two_streams(self) -> bool:
@@ -189,6 +217,13 @@ class _TeacherRuntime:
         return t
 
     def forward_taps(self, videos: torch.Tensor) -> torch.Tensor:
+        cur = self._enter()
+        try:
+            return self._forward_taps(videos)
+        finally:
+            self._leave(cur)
+
+    def _forward_taps(self, videos: torch.Tensor) -> torch.Tensor:
         self.fp.refresh_if_stale()
         ws, D, H, L, HW = self.ws, self.D, self.H, self.L, self.HW
         B, Cc, T, Hh, Ww = videos.shape
@@ -210,18 +245,19 @@ class _TeacherRuntime:
             conv_w = wpad
         patches = ws.get("patches", (Mp, D), BF16)
         ops.gemm(cols, conv_w, patches)
-        x = ws.get("x.a", (Mt, D), F32)
+        RES = BF16 if self.res16 else F32
+        x = ws.get("x.a", (Mt, D), RES)
         ops.clip_embed_ln(patches, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.eps, x, BT, HW, D)
         h = ws.get("h", (Mt, D), BF16)
         qkv = ws.get("qkv", (Mt, 3 * D), BF16)
         o = ws.get("o", (Mt, D), BF16)
         lse = ws.get("lse", (BT, H, L), F32)
-        x1 = ws.get("x1", (Mt, D), F32)
+        x1 = ws.get("x1", (Mt, D), RES)
         a = ws.get("a", (Mt, 4 * D), BF16)
         scale = 64 ** -0.5
         last = self.layers - 1
         pruned_tap = last in self.taps
-        taps_full = {i: ws.get(f"tap.{i}", (Mt, D), F32) for i in self.taps if i != last}     # kept until targets() gathers rows
+        taps_full = {i: ws.get(f"tap.{i}", (Mt, D), RES) for i in self.taps if i != last}     # kept until targets() gathers rows
         self._tap_bufs = [taps_full[i] for i in sorted(taps_full)]
         self._last = dict(x=None, o=o) if pruned_tap else None
 
@@ -300,22 +336,30 @@ class _TeacherRuntime:
             self.taps = taps
 
     def _last_block_rows(self, rows: torch.Tensor, n_rows: int) -> torch.Tensor:
-        """out_proj + MLP of the last block on the listed token rows only -> x_out f32 [n_rows, D] (same arithmetic per row)."""
+        """out_proj + MLP of the last block on the listed token rows only -> x_out [n_rows, D] (same arithmetic per row)."""
         ws, D, w = self.ws, self.D, self.blk[self.layers - 1]
         st = self._last
+        RES = st["x"].dtype
         o_v = ops.gather_rows(st["o"], rows, ws.get("last.o", (n_rows, D), BF16))
-        x_v = ops.gather_rows(st["x"], rows, ws.get("last.x", (n_rows, D), F32))
-        x1 = ws.get("last.x1", (n_rows, D), F32)
+        x_v = ops.gather_rows(st["x"], rows, ws.get("last.x", (n_rows, D), RES))
+        x1 = ws.get("last.x1", (n_rows, D), RES)
         ops.gemm(o_v, w["w_out"], x1, bias=w["b_out"], residual=x_v)
         hh = ws.get("last.h", (n_rows, D), BF16)
         ops.layernorm_fwd(x1, w["ln2"][0], w["ln2"][1], self.eps, hh)
         aa = ws.get("last.a", (n_rows, 4 * D), BF16)
         ops.gemm(hh, w["w_fc"], aa, bias=w["b_fc"], act=ops.ACT_QUICKGELU)
-        xo = ws.get("last.xo", (n_rows, D), F32)
+        xo = ws.get("last.xo", (n_rows, D), RES)
         ops.gemm(aa, w["w_pr"], xo, bias=w["b_pr"], residual=x1)
         return xo
 
     def targets(self, rows: torch.Tensor, n_rows: int, slot: int = 0) -> torch.Tensor:
+        cur = self._enter()
+        try:
+            return self._targets(rows, n_rows, slot)
+        finally:
+            self._leave(cur)
+
+    def _targets(self, rows: torch.Tensor, n_rows: int, slot: int = 0) -> torch.Tensor:
         ws, D, C = self.ws, self.D, self.C
         K = len(self.taps)
         out = ws.get("targets" if slot == 0 else f"targets.{slot}", (K * n_rows, C), F32)

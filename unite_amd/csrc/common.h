@@ -138,6 +138,37 @@ __device__ __forceinline__ void lds_tr_fence() {
     }
 }
 
+// ---- inter-workgroup hand-off inside one launch (cdna_hip_programming.md Guideline 16, counter form) -------------------------------
+// Every workgroup of a group of `expected` calls this AFTER its global stores; it returns true in every thread of the workgroup that
+// arrived LAST, and that workgroup may then read what the others stored with plain loads.  Producer side: every wave drains its stores
+// (vmcnt(0)), workgroup barrier, one lane: agent-scope release, drained again by hand (hipcc may drop the fence's own wait), relaxed
+// agent-scope ticket.  Consumer side (the last arriver only): agent-scope acquire (invalidates this CU's L1), drained, barrier.
+// Nobody waits for anybody: no spin, no residency assumption.  The counter returns to zero (the last arriver resets it), so a
+// workspace header that was zero before the first launch stays usable for ever; `lds_word` is any 4 idle bytes of the ONE LDS array.
+// RELEASE = false: the caller stored EVERY handed-off byte write-through (sc1 / agent-scope relaxed atomic stores), so no L2 write-back is
+// needed (a release with tens of KB freshly dirtied per workgroup costs several us: MI355X_MICROARCH.md, publish-large).
+template <bool RELEASE = true>
+__device__ __forceinline__ bool arrive_last(uint32_t* counter, uint32_t expected, volatile uint32_t* lds_word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (RELEASE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t + 1u == expected;
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *lds_word = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *lds_word != 0u;
+}
+
 // ds_read_b64_tr_b16: within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
 // 4x16 block of 16-bit elements; lane i receives column i of the four rows (row q in element q).
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {

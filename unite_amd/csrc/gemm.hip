@@ -15,6 +15,7 @@
 // The accumulators leave through LDS so that the epilogue (bias, GELU / QuickGELU / GELU', stochastic-depth
 // row scale, residual add, bf16 + f32 outputs) reads and writes 16 B (bf16) / 32 B (f32) per lane.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -40,7 +41,10 @@ struct Params {
     int32_t tile_end[MAX_GROUP];
     int32_t ngroups;
     int32_t splitk, k_chunk;      // K is cut into `splitk` slices of k_chunk (multiple of BK); slice s writes slab s
-    float* slab;                  // f32 [splitk][M][N] partial products (split-K only)
+    float* slab;                  // f32 [splitk][M][N] partial products (split-K only, deep kernels only): the slice of a tile that finishes
+                                  // LAST sums the slabs in slice order (+ the old output if accumulate) and writes the tile
+    uint32_t* counters;           // one arrival counter per output tile (zero outside a launch)
+    float* rowsum_slab;           // f32 [splitk][M] per-slice row sums of op(A) (rowsum_a_out with split-K)
     int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
     float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
@@ -93,10 +97,11 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 // load issued between the stores of two passes could only be waited for together with every store before it.
 __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm_args& g, int slice, int gm, int gn, f32x4 v0, f32x4 v1,
                                                f32x4 b0, f32x4 b1, float* csum = nullptr) {
-    if (p.splitk > 1) {      // raw partial product -> slab; the epilogue runs in splitk_reduce_kernel
-        float* sp = p.slab + ((size_t)slice * g.M + gm) * g.N + gn;
-        *(f32x4*)sp = v0;
-        *(f32x4*)(sp + 4) = v1;
+    if (p.splitk > 1) {      // raw partial product -> slab, write-through (sc1): the tile's last slice to finish reads it in this launch
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)slice * g.M * g.N), 0, 0x7FFFFFF0, 0x00020000);
+        const uint32_t off = (uint32_t)(((size_t)gm * g.N + gn) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0[0]), __float_as_uint(v0[1]), __float_as_uint(v0[2]), __float_as_uint(v0[3])}, rs, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v1[0]), __float_as_uint(v1[1]), __float_as_uint(v1[2]), __float_as_uint(v1[3])}, rs, off + 16, 0, 16);
         return;
     }
     float v[8];
@@ -128,10 +133,19 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
         for (int e = 0; e < 8; ++e) v[e] *= sc;
     }
     if (g.residual) {
-        const float* rp = g.residual + (size_t)gm * g.ldr + gn;
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+        if (g.residual_bf16) {
+            const u32x4 r = *(const u32x4*)((const uint16_t*)g.residual + (size_t)gm * g.ldr + gn);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] += __uint_as_float(r[e] << 16);
+                v[2 * e + 1] += __uint_as_float(r[e] & 0xFFFF0000u);
+            }
+        } else {
+            const float* rp = (const float*)g.residual + (size_t)gm * g.ldr + gn;
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        }
     }
     if (p.debug_skip == 2) {      // timing experiment: everything but the stores
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
@@ -346,6 +360,23 @@ __device__ __forceinline__ bf16x8 load_bfrag_perm(const char* slot, int bcol, in
     }
 }
 
+// Row sums of op(A) beside the product (unite_gemm_args.rowsum_a_out: the bias gradient of a weight-gradient GEMM): the A fragments a
+// wave already holds are multiplied once more, with a B fragment that is 1.0 in column i and 0 elsewhere for m-tile i, so ONE
+// accumulator tile collects the wave's MT row-sum vectors in its columns 0 .. MT-1 (lane (G, c) with c < MT: rows 16 c + 4 G + r).
+template <int MT>
+__device__ __forceinline__ void rowsum_mfma(f32x4& racc, const bf16x8 (&af)[MT][2], int ks_mask, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        if (ks_mask & (1 << ks)) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint32_t w = ((lane & 15) == i) ? 0x3F803F80u : 0u;      // bf16 1.0 | 1.0
+                const u32x4 e = {w, w, w, w};
+                racc = mfma16(af[i][ks], __builtin_bit_cast(bf16x8, e), racc);
+            }
+        }
+}
+
 template <int HALF, bool TA, bool TB>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -420,6 +451,11 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     load_bias8(g, n0 + (tid % (TILE / 8)) * 8, bias0, bias1);
 
     const int arow = wm * (HALF / 2), bcol = wn * 32;
+    // row sums of op(A): the workgroups of column tile 0 only; the (A half, k-step) pairs of a K-tile are dealt over the waves of a row
+    // group (HALF 128: four waves, one pair each; HALF 64: two waves, one half each), +4 MFMAs per K-tile and wave
+    const bool rs_on = p.ngroups == 1 && g.rowsum_a_out != nullptr && n0 == 0;
+    const int rs_h = WN == 4 ? (wn >> 1) : wn, rs_ks = WN == 4 ? (1 << (wn & 1)) : 3;
+    f32x4 racc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nk; ++t) {
         char* set = smem + (t & 1) * (4 * SLOT);
         const char* A0 = set;
@@ -449,6 +485,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma16(af[i][ks], b0f[j][ks], acc[0][i][0][j]);
+        if (rs_on && rs_h == 0) rowsum_mfma<MT>(racc, af, rs_ks, lane);
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 2: quadrant (0,1); needs B1
@@ -485,6 +522,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma16(af[i][ks], b1f[j][ks], acc[1][i][1][j]);
+        if (rs_on && rs_h == 1) rowsum_mfma<MT>(racc, af, rs_ks, lane);
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 4: quadrant (1,0); operands already in registers
@@ -555,6 +593,99 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
             for (int r = 0; r < NG; ++r) a += cs[r * TILE + tid];
             p.colsum_partial[(size_t)(m0 / TILE) * g.N + n0 + tid] = a;
+        }
+    }
+    // ---- row sums of op(A): the waves' partial vectors meet in LDS (k-step slots summed in a fixed order)
+    const int rz_lo = g.rowsum_zero_lo, rz_hi = g.rowsum_zero_hi;
+    if (rs_on) {
+        float* rl = (float*)smem;                     // [2][TILE]: the epilogue image is dead behind its last barrier
+        const int slot = WN == 4 ? (wn & 1) : 0;
+        if (c16 < MT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rl[slot * TILE + rs_h * HALF + arow + c16 * 16 + 4 * G + r] = racc[r];
+        }
+        __syncthreads();
+        if (tid < TILE && m0 + tid < gM) {
+            const int gm = m0 + tid;
+            float v = WN == 4 ? rl[tid] + rl[TILE + tid] : rl[tid];
+            if (p.splitk > 1) __hip_atomic_store(p.rowsum_slab + (size_t)slice * gM + gm, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
+            else {
+                if (gm >= rz_lo && gm < rz_hi) v = 0.f;
+                g.rowsum_a_out[gm] = g.rowsum_accumulate ? g.rowsum_a_out[gm] + v : v;
+            }
+        }
+    }
+    // ---- split-K: the slice of this tile that arrives last adds up the slabs (slice order: bitwise reproducible) and writes the tile
+    if (p.splitk > 1) {
+        if (!arrive_last<false>(p.counters + tile, (uint32_t)p.splitk, (volatile uint32_t*)smem)) return;      // slabs are written through
+        const size_t mn = (size_t)gM * gN;
+        const int S = p.splitk;
+        // One workgroup reads S slabs of its tile: latency-bound unless many loads are in flight.  Batches of NB row chunks x up to SMAX
+        // slices are requested together (16 loads of 16 bytes per thread: 64-128 KB per workgroup in flight), then added in slice order.
+        constexpr int NCH = 2 * (TILE / 32);              // 8-column chunks per thread over the whole tile
+        auto reduce = [&](auto smax_c, auto nb_c) {
+            constexpr int SMAX = decltype(smax_c)::value, NB = decltype(nb_c)::value;
+#pragma unroll 1
+            for (int c0 = 0; c0 < NCH; c0 += NB) {
+                f32x4 a0[NB], a1[NB];
+                bool ok[NB];
+                size_t base[NB], obase[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int ch = c0 + b, h = ch / (TILE / 32), e = ch % (TILE / 32);
+                    const int lr = (tid + e * 4 * HALF) / CPR;
+                    const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
+                    ok[b] = ch < NCH && gm < gM && gn < gN;
+                    base[b] = (size_t)gm * gN + gn;
+                    obase[b] = (size_t)gm * g.ldc + gn;
+                    a0[b] = a1[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll 1
+                for (int s0 = 0; s0 < S; s0 += SMAX) {
+                    f32x4 v[NB][SMAX][2];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int sl = 0; sl < SMAX; ++sl)
+                            if (ok[b] && s0 + sl < S) {
+                                const float* sp = p.slab + (size_t)(s0 + sl) * mn + base[b];
+                                v[b][sl][0] = *(const f32x4*)sp;
+                                v[b][sl][1] = *(const f32x4*)(sp + 4);
+                            }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int sl = 0; sl < SMAX; ++sl)
+                            if (ok[b] && s0 + sl < S) {
+                                if (s0 + sl == 0) { a0[b] = v[b][sl][0]; a1[b] = v[b][sl][1]; }      // the first slab starts the sum: ((s0 + s1) + s2) + ...
+                                else {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) { a0[b][q] += v[b][sl][0][q]; a1[b][q] += v[b][sl][1][q]; }
+                                }
+                            }
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (!ok[b]) continue;
+                    float* op = (float*)g.out + obase[b];
+                    if (g.accumulate) {
+                        const f32x4 o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { a0[b][q] += o0[q]; a1[b][q] += o1[q]; }
+                    }
+                    *(f32x4*)op = a0[b];
+                    *(f32x4*)(op + 4) = a1[b];
+                }
+            }
+        };
+        if (S <= 4) reduce(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+        else reduce(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+        if (rs_on && tid < TILE && m0 + tid < gM) {
+            const int gm = m0 + tid;
+            float v = p.rowsum_slab[gm];
+            for (int sl = 1; sl < S; ++sl) v += p.rowsum_slab[(size_t)sl * gM + gm];
+            if (gm >= rz_lo && gm < rz_hi) v = 0.f;
+            g.rowsum_a_out[gm] = g.rowsum_accumulate ? g.rowsum_a_out[gm] + v : v;
         }
     }
 }
@@ -765,26 +896,6 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
     }
 }
 
-// out[m,n] (+)= sum_s slab[s][m,n]  -- fixed summation order, so weight gradients are bitwise reproducible
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splitk, int M, int N, float* __restrict__ out,
-                                                            int ldc, int accumulate) {
-    const size_t n4 = (size_t)N / 4, total = (size_t)M * n4, mn = (size_t)M * N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t m = i / n4, c = (i % n4) * 4;
-        f32x4 a = *(const f32x4*)(slab + m * N + c);
-        for (int s = 1; s < splitk; ++s) {
-            const f32x4 b = *(const f32x4*)(slab + (size_t)s * mn + m * N + c);
-            a = (f32x4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
-        }
-        float* op = out + m * ldc + c;
-        if (accumulate) {
-            const f32x4 o = *(const f32x4*)op;
-            a = (f32x4){a[0] + o[0], a[1] + o[1], a[2] + o[2], a[3] + o[3]};
-        }
-        *(f32x4*)op = a;
-    }
-}
-
 // colsum_out[n] (+)= sum over tile rows of the per-tile column sums the deep kernels' epilogue left (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
                                                           int accumulate) {
@@ -809,11 +920,16 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // kind 1: 128^2 tile, 512 resident (2 / CU), (c, e) = (1.006, 4.4);  kind 2: 256^2, 256 resident, (1.51, 9.8);
 // kind 3: 128 x 256, 512 resident, (1.58, 9.0).  S > 1 only for plain f32 outputs with a workspace (weight gradients).
 struct Plan { int kind, splitk; double cost; };
-// 0 .. 1: weight of the CU time a launch takes against its latency when the planner picks tile size and split-K (unite_gemm_set_sharing);
-// UNITE_GEMM_PLAN_WORK pins it for experiments
+// 0 .. 1: weight of the CU time a launch takes against its latency when the planner picks tile size and split-K: the PROCESS DEFAULT
+// (unite_gemm_set_sharing; UNITE_GEMM_PLAN_WORK pins it for experiments).  A launch that carries its own hint (unite_gemm_args.plan_*)
+// does not read it.
 double g_plan_work = getenv("UNITE_GEMM_PLAN_WORK") ? atof(getenv("UNITE_GEMM_PLAN_WORK")) : 0.0;
 
-inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only = false) {
+// split-K slabs are summed inside the launch by the last slice of each tile: one workgroup reads S slabs of its tile at the ~100 GB/s
+// a single workgroup gets from L2 / Infinity Cache (MI355X_MICROARCH.md, handoff-payload) -- 2.6 us per 256^2 slab, 0.65 us per 128^2 one
+inline double splitk_tail_us(int kind, int S) { return 1.5 + S * (kind == 2 ? 2.6 : 0.65); }
+
+inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only, double work_weight) {
     const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
     const int slots[4] = {0, 512, 256, 512};
     const double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
@@ -823,17 +939,18 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
         if (only_kind && kind != only_kind) continue;
         if (deep_only && kind == 3) continue;
         for (int S = 1; S <= 16; ++S) {
-            if (S > 1 && (!can_split || (size_t)S * M * N * sizeof(float) > ws_bytes || kt / S < 4)) break;
+            // split-K: deep kernels only (they carry the in-launch reduction), one counter per tile in the workspace header
+            if (S > 1 && (!can_split || kind == 3 || tiles[kind] > 4096 || (size_t)S * M * N * sizeof(float) > ws_bytes || kt / S < 4)) break;
             const int kts = (kt + S - 1) / S;
             const double rounds = (double)((tiles[kind] * S + slots[kind] - 1) / slots[kind]);
             double cost = rounds * (kts * cc[kind] + ee[kind]);
-            if (S > 1) cost += 3.0 + (double)S * M * N * 8.0 / 5.0e6;      // slab write + read at ~5 TB/s, one more launch
-            // g_plan_work > 0: the launch shares the GPU with an independent stream (teacher one batch ahead), so what it costs the step is
-            // less its own latency than the CU time it takes: workgroups x time each, over the resident slots, + the reduction pass
-            if (g_plan_work > 0.0) {
+            if (S > 1) cost += splitk_tail_us(kind, S);
+            // work_weight > 0: the launch shares the GPU with an independent stream (teacher one batch ahead), so what it costs the step is
+            // less its own latency than the CU time it takes: workgroups x time each, over the resident slots (+ the reducing workgroups' tails)
+            if (work_weight > 0.0) {
                 double work = (double)tiles[kind] * S * (kts * cc[kind] + ee[kind]) / slots[kind];
-                if (S > 1) work += (double)S * M * N * 8.0 / 5.0e6;
-                cost = (1.0 - g_plan_work) * cost + g_plan_work * work;
+                if (S > 1) work += (double)tiles[kind] * splitk_tail_us(kind, S) / slots[kind];
+                cost = (1.0 - work_weight) * cost + work_weight * work;
             }
             if (cost < best.cost - 1e-9) best = {kind, S, cost};
         }
@@ -847,8 +964,22 @@ struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     double flops = 0.0;
+    double bytes = 0.0;           // algorithmic HBM bytes of the timed launches: every operand / output / residual / aux matrix once
 };
 ProfState g_prof;
+
+// operands once, outputs once, f32 or bf16 residual / saved pre-activations / old output once: the floor the PMC traffic is compared with
+inline double algo_bytes(const unite_gemm_args& g) {
+    const double mn = (double)g.M * g.N;
+    double b = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + mn * (g.out_f32 ? 4.0 : 2.0);
+    if (g.bias) b += 4.0 * g.N;
+    if (g.residual) b += mn * (g.residual_bf16 ? 2.0 : 4.0);
+    if (g.act == UNITE_ACT_DGELU && g.aux_in) b += mn * 2.0;
+    if (g.act == UNITE_ACT_GELU && g.aux_out) b += mn * 2.0;
+    if (g.accumulate) b += mn * 4.0;
+    if (g.out_bf16_copy) b += mn * 2.0;
+    return b;
+}
 
 }  // namespace
 
@@ -863,7 +994,8 @@ int check_problem(const unite_gemm_args& g, int64_t& a_bytes, int64_t& b_bytes) 
     if (g.act == UNITE_ACT_DGELU && (!g.aux_in || (g.ld_aux_in & 7))) return UNITE_EINVAL;
     if (g.aux_out && (g.ld_aux_out & 7)) return UNITE_EINVAL;
     if (g.row_scale && g.rows_per_scale <= 0) return UNITE_EINVAL;
-    if (g.residual && (g.ldr & 3)) return UNITE_EINVAL;
+    if (g.residual && ((g.ldr & (g.residual_bf16 ? 7 : 3)) || !aligned16(g.residual))) return UNITE_EINVAL;
+    if ((g.plan_flags & 1) && (g.plan_persistent < 0 || g.plan_persistent > 2)) return UNITE_EINVAL;
     if (g.out_bf16_copy && (g.ld_copy & 7)) return UNITE_EINVAL;
     const int64_t a_rows = g.trans_a ? g.K : g.M, a_cols = g.trans_a ? g.M : g.K;
     const int64_t b_rows = g.trans_b ? g.K : g.N, b_cols = g.trans_b ? g.N : g.K;
@@ -914,7 +1046,10 @@ extern "C" int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t coun
     if (prof) {
         (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
         g_prof.used++;
-        for (int i = 0; i < count; ++i) g_prof.flops += 2.0 * args[i].M * args[i].N * args[i].K;
+        for (int i = 0; i < count; ++i) {
+            g_prof.flops += 2.0 * args[i].M * args[i].N * args[i].K;
+            g_prof.bytes += algo_bytes(args[i]);
+        }
     }
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -959,7 +1094,7 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         // bf16 products (qkv -14 %, fc1 -3 %).  The teacher's 310-MB bf16 outputs (QuickGELU c_fc, qkv: +1 .. +5 %) and the k-strided B of
         // the input gradients (+10 .. +18 %: transposing fragment reads with rebuilt addresses) stay on the tile kernels.
         // UNITE_GEMM_PP = 0 never / 1 measured shapes (default) / 2 whenever supported; UNITE_GEMM_PP_MIN_TILES moves the size floor.
-        const int pp = g_pp_policy >= 0 ? g_pp_policy : g_pp_env();
+        const int pp = (g.plan_flags & 1) ? g.plan_persistent : (g_pp_policy >= 0 ? g_pp_policy : g_pp_env());
         static const int pp_min = getenv("UNITE_GEMM_PP_MIN_TILES") ? atoi(getenv("UNITE_GEMM_PP_MIN_TILES")) : 64;
         static const char* force_k = getenv("UNITE_GEMM_KERNEL");
         // a launch of 257 .. ~1000 tiles gives the 256 persistent workgroups 1-4 tiles each: badly balanced, most of the epilogues unhidden,
@@ -970,7 +1105,7 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         const int pp_tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
         const bool measured = !g.trans_b && (pp_tiles <= band_lo || pp_tiles >= band_hi) &&
                               (g.out_f32 || (g.act != UNITE_ACT_QUICKGELU && (int64_t)g.M * g.N <= (int64_t)32 << 20));
-        if (pp && (pp == 2 || measured) && !force_k && ((g.M + 255) / 256) * ((g.N + 127) / 128) >= pp_min && unite_gemm_pp_supported(g)) {
+        if (pp && (pp == 2 || measured) && !force_k && !g.rowsum_a_out && ((g.M + 255) / 256) * ((g.N + 127) / 128) >= pp_min && unite_gemm_pp_supported(g)) {
             hipStream_t s = (hipStream_t)stream;
             const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
@@ -979,6 +1114,7 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
                 (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
                 g_prof.used++;
                 g_prof.flops += 2.0 * g.M * g.N * g.K;
+                g_prof.bytes += algo_bytes(g);
             }
             return rc;
         }
@@ -993,16 +1129,34 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     static const char* force = getenv("UNITE_GEMM_KERNEL");
     const int only = !force ? 0 : !strcmp(force, "deep256") ? 2 : !strcmp(force, "wide") ? 3 : 1;
     const bool plain = g.out_f32 && !g.bias && g.act == UNITE_ACT_NONE && !g.row_scale && !g.residual && !g.out_bf16_copy;
-    const bool can_split = plain && g.workspace && aligned16(g.workspace);
+    // workspace: [header: tile arrival counters][per-slice row sums of op(A), 16 x M floats][slabs]
+    const bool want_rowsum = g.rowsum_a_out != nullptr;
+    const size_t rs_bytes = want_rowsum ? (((size_t)16 * g.M * sizeof(float) + 255) & ~(size_t)255) : 0;
+    const size_t ws_head = UNITE_WS_HEADER_BYTES + rs_bytes;
+    const bool can_split = plain && g.workspace && aligned16(g.workspace) && (size_t)g.workspace_bytes > ws_head;
     // column sums of the output come out of the deep kernels' epilogue (per-tile-row partials in the workspace, then one small
     // reduction): no split-K, no wide / simple kernel for such a product
     const bool want_colsum = g.colsum_out != nullptr;
     if (want_colsum && (!g.workspace || !aligned16(g.workspace) ||
                         (size_t)g.workspace_bytes < unite_gemm_colsum_workspace(g.M, g.N) || (((uintptr_t)g.colsum_out) & 3))) return UNITE_EINVAL;
-    const Plan plan = plan_gemm(g.M, g.N, g.K, can_split && !want_colsum, (size_t)g.workspace_bytes, want_colsum && only != 2 ? (only == 3 ? 0 : only) : only,
-                                want_colsum);
-    const int kind = (force && !strcmp(force, "simple") && !want_colsum) ? 0 : plan.kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2, 3 wide
-    p.colsum_partial = want_colsum ? (float*)g.workspace : nullptr;
+    if (want_rowsum && (want_colsum || (((uintptr_t)g.rowsum_a_out) & 3) || g.rowsum_zero_lo > g.rowsum_zero_hi)) return UNITE_EINVAL;
+    const bool deep_only = want_colsum || want_rowsum;
+    const double work_weight = (g.plan_flags & 2) ? (double)g.plan_sharing : g_plan_work;
+    if (!(work_weight >= 0.0 && work_weight <= 1.0)) return UNITE_EINVAL;
+    Plan plan = plan_gemm(g.M, g.N, g.K, can_split && !want_colsum, can_split ? (size_t)g.workspace_bytes - ws_head : 0,
+                          deep_only && only != 2 ? (only == 3 ? 0 : only) : only, deep_only, work_weight);
+    // tuning aid: UNITE_GEMM_FORCE_PLAN="kind,S" pins tile kernel (1: 128^2, 2: 256^2) and split factor for products that may split
+    static const char* force_plan = getenv("UNITE_GEMM_FORCE_PLAN");
+    if (force_plan && can_split && !want_colsum) {
+        const int fk = atoi(force_plan), fs = strchr(force_plan, ',') ? atoi(strchr(force_plan, ',') + 1) : 1;
+        const int kt = (g.K + BK - 1) / BK;
+        if ((fk == 1 || fk == 2) && fs >= 1 && fs <= 16 && kt / fs >= 1 &&
+            (size_t)fs * g.M * g.N * sizeof(float) <= (size_t)g.workspace_bytes - ws_head) plan = {fk, fs, 0.0};
+    }
+    static const bool plan_dbg = getenv("UNITE_GEMM_PLAN_DEBUG") != nullptr;
+    if (plan_dbg) fprintf(stderr, "[unite_gemm] M %d N %d K %d ta %d tb %d w %.2f -> kind %d S %d\n", g.M, g.N, g.K, g.trans_a, g.trans_b, work_weight, plan.kind, plan.splitk);
+    const int kind = (force && !strcmp(force, "simple") && !deep_only) ? 0 : plan.kind;      // 0 simple 128^2, 1 deep 128^2, 2 deep 256^2, 3 wide
+    p.colsum_partial = want_colsum ? (float*)((char*)g.workspace + UNITE_WS_HEADER_BYTES) : nullptr;      // the header stays zero for split-K users of the same buffer
     const int tiles = kind == 2 ? ((g.M + 255) / 256) * ((g.N + 255) / 256)
                     : kind == 3 ? ((g.M + 127) / 128) * ((g.N + 255) / 256) : ((g.M + 127) / 128) * ((g.N + 127) / 128);
     p.splitk = 1;
@@ -1015,10 +1169,12 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     // (32 B per lane) measured slower with sc1 and keep plain stores.  UNITE_GEMM_NT = 0 | 1 (nt) | 2 (sc1) overrides.
     static const int nt = getenv("UNITE_GEMM_NT") ? atoi(getenv("UNITE_GEMM_NT")) : -1;
     p.nt_store = nt >= 0 ? nt : ((!g.out_f32 && (size_t)g.M * g.N * 2 > (32u << 20)) ? 2 : 0);
-    if (plan.splitk > 1) {
+    if (plan.splitk > 1 && kind != 0) {
         p.k_chunk = ((g.K + plan.splitk - 1) / plan.splitk + BK - 1) / BK * BK;
         p.splitk = (g.K + p.k_chunk - 1) / p.k_chunk;      // drop empty trailing slices
-        p.slab = (float*)g.workspace;
+        p.counters = (uint32_t*)g.workspace;
+        p.rowsum_slab = (float*)((char*)g.workspace + UNITE_WS_HEADER_BYTES);
+        p.slab = (float*)((char*)g.workspace + ws_head);
     }
     const int nb = tiles * p.splitk;
     hipStream_t s = (hipStream_t)stream;
@@ -1062,12 +1218,6 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
-    if (p.splitk > 1) {
-        const size_t total4 = (size_t)g.M * g.N / 4;
-        const unsigned grid = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)p.slab, p.splitk, g.M, g.N, (float*)g.out, g.ldc,
-                           g.accumulate);
-    }
     if (want_colsum) {
         const int tile_m = kind == 2 ? 256 : 128;
         hipLaunchKernelGGL(colsum_rows_kernel, dim3((g.N + 63) / 64), dim3(256), 0, s, (const float*)p.colsum_partial, (g.M + tile_m - 1) / tile_m,
@@ -1077,12 +1227,15 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
         g_prof.used++;
         g_prof.flops += 2.0 * g.M * g.N * g.K;
+        g_prof.bytes += algo_bytes(g);
     }
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
 
-extern "C" size_t unite_gemm_colsum_workspace(int32_t M, int32_t N) { return (size_t)((M + 127) / 128) * (size_t)N * sizeof(float); }
+extern "C" size_t unite_gemm_colsum_workspace(int32_t M, int32_t N) {
+    return UNITE_WS_HEADER_BYTES + (size_t)((M + 127) / 128) * (size_t)N * sizeof(float);
+}
 
 // the same timing pool for the other MFMA kernel of the step (teacher_fused.hip); not part of the C ABI
 bool unite_prof_begin(hipStream_t s) {
@@ -1090,10 +1243,11 @@ bool unite_prof_begin(hipStream_t s) {
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
     return prof;
 }
-void unite_prof_end(hipStream_t s, double flops) {
+void unite_prof_end(hipStream_t s, double flops, double bytes) {
     (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
     g_prof.used++;
     g_prof.flops += flops;
+    g_prof.bytes += bytes;
 }
 
 // ---- diagnostics (bench.py): HIP events around every GEMM launch, on the stream it is launched on
@@ -1106,12 +1260,13 @@ extern "C" int unite_prof_enable(int32_t on, int32_t max_launches) {
         }
         g_prof.used = 0;
         g_prof.flops = 0.0;
+        g_prof.bytes = 0.0;
     }
     g_prof.on = on != 0;
     return UNITE_OK;
 }
 
-extern "C" int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops) {
+extern "C" int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops, double* total_bytes) {
     double ms = 0.0;
     for (size_t i = 0; i < g_prof.used; ++i) {
         float t = 0.f;
@@ -1122,5 +1277,6 @@ extern "C" int unite_prof_summary(double* total_ms, int64_t* launches, double* t
     if (total_ms) *total_ms = ms;
     if (launches) *launches = (int64_t)g_prof.used;
     if (total_flops) *total_flops = g_prof.flops;
+    if (total_bytes) *total_bytes = g_prof.bytes;
     return UNITE_OK;
 }

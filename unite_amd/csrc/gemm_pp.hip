@@ -40,6 +40,8 @@ struct PPParams {
     int32_t nbm, nbn, ntiles, nk;
     uint32_t rps_magic;                       // ceil(2^32 / rows_per_scale): row / rows_per_scale = umulhi(row, magic), exact for row < 2^20, divisor in [2, 2^12]
     int32_t wt_store;                         // large bf16 outputs are written through (sc1) so that they do not evict the operand panels from the L2
+    int32_t res16;                            // bf16 output + bf16 residual (unite_gemm_args.residual_bf16): the residual rows travel in the aux_in slot
+    int32_t ld_aux;                           // row stride of whatever the aux_in slot reads (saved pre-activations or the bf16 residual)
 };
 
 __device__ __forceinline__ int swz256p(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -215,7 +217,7 @@ __device__ __forceinline__ void epi_issue_loads(const PPParams& p, const Descs& 
         asm_load_b128(e.r1, (okn && gmA + 8 < g.M) ? (uint32_t)((gmA + 8) * g.ldr + gl) * 4u : OOB_OFFSET, d.res);   // operation B
         asm_load_b32(e.sc, okm ? __umulhi((uint32_t)gm, p.rps_magic) * 4u : OOB_OFFSET, d.scale);
     } else {
-        asm_load_b128(e.r0, (okm && gn < g.N) ? (uint32_t)(gm * g.ld_aux_in + gn) * 2u : OOB_OFFSET, d.aux_in);      // 8 bf16 pre-activations
+        asm_load_b128(e.r0, (okm && gn < g.N) ? (uint32_t)(gm * p.ld_aux + gn) * 2u : OOB_OFFSET, d.aux_in);      // 8 bf16 pre-activations / residual values
     }
 }
 
@@ -274,6 +276,13 @@ __device__ __forceinline__ EpiOut epi_math(const PPParams& p, EpiRegs& e, const 
             for (int r = 0; r < 4; ++r) {
                 v[2 * r] *= gelu_erf_grad(__uint_as_float(z[r] << 16));
                 v[2 * r + 1] *= gelu_erf_grad(__uint_as_float(z[r] & 0xFFFF0000u));
+            }
+        } else if (p.res16) {
+            const u32x4 z = __builtin_bit_cast(u32x4, e.r0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[2 * r] += __uint_as_float(z[r] << 16);
+                v[2 * r + 1] += __uint_as_float(z[r] & 0xFFFF0000u);
             }
         }
         out.o0 = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const PPParams p) {
     d.out = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, (int)p.out_bytes, 0x00020000);
     d.res = __builtin_amdgcn_make_buffer_rsrc((void*)g.residual, 0, (int)p.res_bytes, 0x00020000);
     d.bias = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, (int)p.bias_bytes, 0x00020000);
-    d.aux_in = __builtin_amdgcn_make_buffer_rsrc((void*)g.aux_in, 0, (int)p.aux_in_bytes, 0x00020000);
+    d.aux_in = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res16 ? g.residual : g.aux_in), 0, (int)p.aux_in_bytes, 0x00020000);
     d.aux_out = __builtin_amdgcn_make_buffer_rsrc((void*)g.aux_out, 0, (int)p.aux_out_bytes, 0x00020000);
     d.scale = __builtin_amdgcn_make_buffer_rsrc((void*)g.row_scale, 0, (int)p.scale_bytes, 0x00020000);
     const LaneOffs lofs = lane_offsets<TB, PERM>(g, wave, lane);
@@ -557,12 +566,14 @@ int unite_gemm_pp_supported(const unite_gemm_args& g) {
     const int64_t mx = 0x7FFFFFF0;
     if (g.out_f32) {
         if (g.act != UNITE_ACT_NONE || g.aux_out || g.aux_in) return 0;
-        if (g.residual && ((g.ldr & 3) || !aligned16p(g.residual))) return 0;
+        if (g.residual && (g.residual_bf16 || (g.ldr & 3) || !aligned16p(g.residual))) return 0;
         if (((int64_t)(g.M - 1) * g.ldc + g.N) * 4 >= mx) return 0;
         if (g.residual && ((int64_t)(g.M - 1) * g.ldr + g.N) * 4 >= mx) return 0;
         if (g.row_scale && (g.rows_per_scale < 2 || g.rows_per_scale > 4096 || g.M >= (1 << 20))) return 0;
     } else {
-        if (g.residual || g.row_scale) return 0;
+        if (g.row_scale) return 0;
+        if (g.residual && (!g.residual_bf16 || g.act != UNITE_ACT_NONE || g.aux_out || (g.ldr & 7) || !aligned16p(g.residual) ||
+                           ((int64_t)(g.M - 1) * g.ldr + g.N) * 2 >= mx)) return 0;
         if (g.act == UNITE_ACT_DGELU && (!g.aux_in || !aligned16p(g.aux_in))) return 0;
         if (g.aux_out && (g.act != UNITE_ACT_GELU || !aligned16p(g.aux_out))) return 0;
         if (((int64_t)(g.M - 1) * g.ldc + g.N) * 2 >= mx) return 0;
@@ -579,9 +590,12 @@ int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_by
     p.b_bytes = (uint32_t)b_bytes;
     const int esz = g.out_f32 ? 4 : 2;
     p.out_bytes = (uint32_t)(((int64_t)(g.M - 1) * g.ldc + g.N) * esz);
-    p.res_bytes = g.residual ? (uint32_t)(((int64_t)(g.M - 1) * g.ldr + g.N) * 4) : 0u;
+    p.res16 = (!g.out_f32 && g.residual && g.residual_bf16) ? 1 : 0;
+    p.res_bytes = (g.residual && !p.res16) ? (uint32_t)(((int64_t)(g.M - 1) * g.ldr + g.N) * 4) : 0u;
     p.bias_bytes = g.bias ? (uint32_t)g.N * 4u : 0u;
-    p.aux_in_bytes = (g.aux_in && g.act == UNITE_ACT_DGELU) ? (uint32_t)(((int64_t)(g.M - 1) * g.ld_aux_in + g.N) * 2) : 0u;
+    p.ld_aux = p.res16 ? g.ldr : g.ld_aux_in;
+    p.aux_in_bytes = p.res16 ? (uint32_t)(((int64_t)(g.M - 1) * g.ldr + g.N) * 2)
+                   : (g.aux_in && g.act == UNITE_ACT_DGELU) ? (uint32_t)(((int64_t)(g.M - 1) * g.ld_aux_in + g.N) * 2) : 0u;
     p.aux_out_bytes = (g.aux_out && g.act == UNITE_ACT_GELU) ? (uint32_t)(((int64_t)(g.M - 1) * g.ld_aux_out + g.N) * 2) : 0u;
     p.scale_bytes = g.row_scale ? (uint32_t)((g.M + g.rows_per_scale - 1) / g.rows_per_scale) * 4u : 0u;
     p.rps_magic = g.row_scale ? (uint32_t)((0x100000000ull + (uint64_t)g.rows_per_scale - 1) / (uint64_t)g.rows_per_scale) : 0u;

@@ -50,10 +50,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------ column sums (bias gradients)
 constexpr int CS_ROWS = 256;   // rows per workgroup
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __restrict__ x, int ldx, int M, int N,
-                                                             float* __restrict__ partial) {
-    // block (bx, by): columns [bx*512, +512) as 64 lanes x 8, rows [by*256, +256) split over 4 waves
+constexpr int CS_HEADER = 4096;  // arrival counters, one per 512-column block (zero outside a launch); N <= 512 * 1024
+// block (bx, by): columns [bx*512, +512) as 64 lanes x 8, rows [by*256, +256) split over 4 waves -> partial[by][n]; the LAST row block of
+// a column block to finish (arrive_last: nobody waits) adds the partial rows in order (bitwise reproducible) and writes the 512 sums
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, int ldx, int M, int N, char* __restrict__ workspace,
+                                                     float* __restrict__ out, int accumulate, int zero_lo, int zero_hi) {
     __shared__ float red[4][512];
+    __shared__ uint32_t last_word;
+    float* const partial = (float*)(workspace + CS_HEADER);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 512 + lane * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -75,21 +79,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
         const int gc = blockIdx.x * 512 + c;
         if (gc < N) partial[(size_t)blockIdx.y * N + gc] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     }
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
-                                                           int accumulate, int zero_lo, int zero_hi) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-    float a = 0.f;
-    if (c < N)
-        for (int i = r; i < nparts; i += 4) a += partial[(size_t)i * N + c];
-    red[r][threadIdx.x & 63] = a;
-    __syncthreads();
-    if (r == 0 && c < N) {
-        const int l = threadIdx.x;
-        a = red[0][l] + red[1][l] + red[2][l] + red[3][l];
-        if (c >= zero_lo && c < zero_hi) a = 0.f;
-        out[c] = accumulate ? out[c] + a : a;
+    const int nparts = (int)gridDim.y;
+    if (!arrive_last((uint32_t*)workspace + blockIdx.x, (uint32_t)nparts, &last_word)) return;
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc >= N) continue;
+        float a = 0.f;
+        int i = 0;
+        for (; i + 8 <= nparts; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(i + u) * N + gc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; i < nparts; ++i) a += partial[(size_t)i * N + gc];
+        if (gc >= zero_lo && gc < zero_hi) a = 0.f;
+        out[gc] = accumulate ? out[gc] + a : a;
     }
 }
 
@@ -604,18 +610,17 @@ extern "C" int unite_gather_rows_f32(const float* table, const int32_t* index, i
 }
 
 extern "C" size_t unite_colsum_workspace(int32_t M, int32_t N) {
-    return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
+    return CS_HEADER + (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float);
 }
 
 extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, int32_t zero_lo,
                                  int32_t zero_hi, void* workspace, void* stream) {
-    if (!x || !out || !workspace || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UNITE_EINVAL;
+    if (!x || !out || !workspace || M <= 0 || N <= 0 || (N & 7) || (ldx & 7) || (N + 511) / 512 > CS_HEADER / 4) return UNITE_EINVAL;
     const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
+    if (nparts > 65535) return UNITE_ENOSUP;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N,
-                       (float*)workspace);
-    UNITE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)workspace, nparts, N, out, accumulate, zero_lo, zero_hi);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N, (char*)workspace, out,
+                       accumulate, zero_lo, zero_hi);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

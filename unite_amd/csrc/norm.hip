@@ -3,6 +3,7 @@
 // All of them are HBM-bound streaming kernels: 16-byte loads, 8/16-byte stores, no LDS except for the
 // per-workgroup partial sums of the gamma/beta gradients.
 #include "common.h"
+#include <stdint.h>
 
 namespace {
 
@@ -20,6 +21,20 @@ __device__ __forceinline__ void load_row(const float* row, int D, int lane, f32x
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         v[i] = (c < D) ? *(const f32x4*)(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// the same row from a bf16 matrix (the frozen teacher's bf16 residual stream): 8 bytes per lane and piece
+template <int NV>
+__device__ __forceinline__ void load_row_bf16(const uint16_t* row, int D, int lane, f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const u32x2 w = *(const u32x2*)(row + c);
+            v[i] = (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
+                           __uint_as_float(w[1] & 0xFFFF0000u)};
+        } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -47,8 +62,8 @@ __device__ __forceinline__ void store4(void* y, int y_f32, size_t off, f32x4 o) 
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ row_index,
+template <int NV, bool XBF>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x, int ldx, const int32_t* __restrict__ row_index,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ post_add, void* __restrict__ y, int y_f32,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D) {
@@ -57,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (row >= M) return;
     const int src = row_index ? row_index[row] : row;
     f32x4 v[NV];
-    load_row<NV>(x + (size_t)src * ldx, D, lane, v);
+    if (XBF) load_row_bf16<NV>((const uint16_t*)x + (size_t)src * ldx, D, lane, v);
+    else load_row<NV>((const float*)x + (size_t)src * ldx, D, lane, v);
     float mean, rstd;
     row_stats<NV>(v, D, lane, eps, mean, rstd);
     if (lane == 0) {
@@ -180,8 +196,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // out_k[c] (+)= sum_b partial[b][k][c], k = 0..2; fixed order -> deterministic.
 // Grid (D / 32, 3): one workgroup per output vector k and 32 columns; thread (r, c) = (tid >> 5, tid & 31) sums partial rows
 // r, r + 8, ... (128-B coalesced, 8 independent loads in flight per thread), then the 8 row groups are combined through LDS in a
-// fixed order.  (The first version -- 16 columns x 16 row groups, all three vectors per workgroup -- ran only D / 16 = 48
-// workgroups with 64-B segments: 14.7 us per call, 36 calls per step.)
+// fixed order.  Round 3 tried to fold this second stage into the backward kernels themselves (groups of 32 workgroups, the last one of
+// a group to finish adds the group's partials, the last group adds the groups: common.h arrive_last): layernorm_bwd went from 28.9 to
+// 73.5 us per call at 10 240 rows -- 640 x 9 KB of partials want ~70 workgroups reading in parallel, and only the ONE workgroup that
+// arrives last can know that the others are done -- against 28.9 + 5.7 us for the two launches.  Reverted; the split-K slabs of the
+// weight-gradient GEMMs (a few tiles per slab set) and the column sums do fold into their kernels (gemm.hip, misc.hip).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* __restrict__ out_a, float* __restrict__ out_b, float* __restrict__ out_c,
                                                               int accumulate) {
@@ -372,8 +391,8 @@ __global__ __launch_bounds__(256) void decoder_tail_bwd_kernel(const float* __re
 template <int NV>
 __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const uint16_t* __restrict__ patches, const float* __restrict__ cls,
                                                             const float* __restrict__ pos, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps, float* __restrict__ x,
-                                                            int BT, int HW, int D) {
+                                                            const float* __restrict__ beta, float eps, void* __restrict__ x,
+                                                            int x_f32, int BT, int HW, int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int L = HW + 1;
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const uint16_t* __re
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            *(f32x4*)(x + (size_t)row * D + c) = o;
+            store4(x, x_f32, (size_t)row * D + c, o);
         }
     }
 }
@@ -447,7 +466,18 @@ extern "C" int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* r
                                    int32_t M, int32_t D, void* stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, false>), dim3((M + 3) / 4), dim3(256), 0, s, (const void*)x, ldx, row_index,
+                                      gamma, beta, eps, post_add, y, y_f32, mean, rstd, M, D));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_layernorm_fwd_bf16in(const void* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                                          float eps, const float* post_add, void* y, int32_t y_f32, float* mean, float* rstd,
+                                          int32_t M, int32_t D, void* stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3) || (((uintptr_t)x) & 7)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, true>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
                                       beta, eps, post_add, y, y_f32, mean, rstd, M, D));
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -466,10 +496,10 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     if (row_scale && rows_per_scale <= 0) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (M + bwd_rows_per_block(M) - 1) / bwd_rows_per_block(M);
+    if (dxsum && !dx_bf16) return UNITE_EINVAL;
     DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma,
                                       dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
     UNITE_LAUNCH_CHECK();
-    if (dxsum && !dx_bf16) return UNITE_EINVAL;
     if (dgamma || dbeta || dxsum) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32, 3), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
                            dbeta, dxsum, accumulate);
@@ -507,14 +537,14 @@ extern "C" int unite_decoder_tail_bwd(const float* y, const float* gamma, const 
 }
 
 extern "C" int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,
-                                   const float* gamma, const float* beta, float eps, float* x, int32_t BT, int32_t HW, int32_t D,
-                                   void* stream) {
+                                   const float* gamma, const float* beta, float eps, void* x, int32_t x_f32, int32_t BT, int32_t HW,
+                                   int32_t D, void* stream) {
     if (!patches || !class_embedding || !positional_embedding || !gamma || !beta || !x || BT <= 0 || HW <= 0 || !dim_ok(D))
         return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int rows = BT * (HW + 1);
     DISPATCH_NV(D, hipLaunchKernelGGL((clip_embed_ln_kernel<NV>), dim3((rows + 3) / 4), dim3(256), 0, s, (const uint16_t*)patches,
-                                      class_embedding, positional_embedding, gamma, beta, eps, x, BT, HW, D));
+                                      class_embedding, positional_embedding, gamma, beta, eps, x, x_f32, BT, HW, D));
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t
 }  // namespace
 
 bool unite_prof_begin(hipStream_t s);                  // gemm.hip: bench.py's launch-timing pool
-void unite_prof_end(hipStream_t s, double flops);
+void unite_prof_end(hipStream_t s, double flops, double bytes);
 
 extern "C" int unite_teacher_qkv_attn(const void* h, const void* w_in, const float* b_in, void* out, int32_t BT, int32_t L, int32_t H,
                                       int32_t D, float scale, void* stream) {
@@ -251,7 +251,8 @@ extern "C" int unite_teacher_qkv_attn(const void* h, const void* w_in, const flo
     const bool prof = unite_prof_begin((hipStream_t)stream);
     hipLaunchKernelGGL(teacher_qkv_attn_kernel, dim3(BT * H), dim3(512), FQ_LDS, (hipStream_t)stream, (const uint16_t*)h, (const uint16_t*)w_in,
                        b_in, (uint16_t*)out, L, H, D, scale, (uint32_t)h_bytes, (uint32_t)w_bytes);
-    if (prof) unite_prof_end((hipStream_t)stream, 2.0 * BT * L * 3.0 * D * D + 4.0 * BT * H * (double)L * L * 64.0);
+    if (prof) unite_prof_end((hipStream_t)stream, 2.0 * BT * L * 3.0 * D * D + 4.0 * BT * H * (double)L * L * 64.0,
+                             2.0 * (2.0 * BT * L * D + 3.0 * D * D) + 12.0 * D);      // h in, out, w_in, b_in
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

@@ -179,39 +179,32 @@ def stage1_step(model, teacher_model, videos, n_source, mask_ratio, mask_type, b
     return student_phase(model, videos, tout, n_source, clip_loss_data, clip_loss_type)
 
 
-class TeacherAhead:
-    """The frozen teacher one batch ahead of the student: ``launch(videos)`` enqueues the whole teacher phase of a batch on a stream of
-    its own and returns its TeacherOut; the caller then trains the student on the PREVIOUS batch, whose teacher phase was launched an
-    iteration earlier.  Nothing in the teacher depends on the student (frozen, no_grad: run_stage1.py:371), so the arithmetic of every
-    step is that of stage1_step; what changes is that the student's many short, partially filled launches (and, on N GPUs, its gradient
-    all-reduces) share the GPU with the teacher's long GEMMs.  Outputs rotate through ``n_slots`` (three) slots.
+class AheadStream:
+    """What TeacherAhead (stage 1) and MaskTeacherAhead (stage 3) share: a stream of their own for the frozen teacher, output slots that
+    rotate, the ordering of the teacher's INPUTS, and the planner hints its GEMM launches carry (per call, inside unite_gemm_args: no
+    process-wide setting is touched, include/unite_hip.h ABI 2)."""
 
-    Measured on MI355X (B = 32, DESIGN.md section 5): 23.7 -> 21.6 ms per step, 20.4 with the GEMM planner told that launches share the
-    GPU (unite_gemm_set_sharing: larger tiles, fewer split-K slices).  Beside a concurrent student the teacher is best left on ONE
-    stream (its three frame-range streams: +0.4 ms) and on the tile GEMM kernels (the persistent kernel keeps every CU for a whole launch,
-    so nothing of the student slips in between its tiles: +0.2 ms); UNITE_TEACHER_AHEAD_STREAMS / UNITE_TEACHER_PP change that."""
-
-    def __init__(self, teacher_model, state: StepState, device, mask_ratio, mask_type, clip_input_resolution=224):
-        self.teacher, self.state = teacher_model, state
-        self.mask_ratio, self.mask_type, self.res = mask_ratio, mask_type, clip_input_resolution
+    def __init__(self, device, n_slots: int):
         self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("UNITE_TEACHER_AHEAD_PRIO", "0")))
         self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
         self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))          # -1: whatever the process-wide policy is
-        self.n_slots = max(2, int(os.environ.get("UNITE_TEACHER_AHEAD_SLOTS", "3")))
+        # both phases share the GPU: the GEMM planner weighs the CU time of a launch against its latency (include/unite_hip.h).  The weight
+        # travels with every launch of the teacher phase (hints()) and of the student step (student())
+        self.sharing = float(os.environ.get("UNITE_GEMM_SHARING", "0.8"))
+        self.n_slots = max(2, n_slots)
         self.n = 0
-        # both phases now share the GPU: the GEMM planner weighs the CU time of a launch against its latency (include/unite_hip.h)
-        from . import _lib
-        lib = _lib.load()
-        self._sharing_before = lib.unite_gemm_get_sharing()
-        lib.unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
         self._marks = []                   # events on the student's stream, one per launch
 
+    def hints(self):
+        """context: GEMM launches of the teacher phase"""
+        return ops.plan(persistent=self.gemm_policy if self.gemm_policy >= 0 else None, sharing=self.sharing)
+
+    def student(self):
+        """context: GEMM launches of the student step that runs beside the teacher phase of the next batch"""
+        return ops.plan(sharing=self.sharing)
+
     def close(self):
-        """back to the planner setting found at construction (the launches already enqueued keep theirs); idempotent"""
-        if self._sharing_before is not None:
-            from . import _lib
-            _lib.load().unite_gemm_set_sharing(self._sharing_before)
-            self._sharing_before = None
+        """kept for callers of round 2 (the planner weight was a process-wide setting then; now every launch carries its own)"""
 
     def __enter__(self):
         return self
@@ -219,39 +212,57 @@ class TeacherAhead:
     def __exit__(self, *exc):
         self.close()
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def launch(self, videos, bool_masked_pos=None, importance=None) -> TeacherOut:
-        """``videos`` may still be on the host: the copy then goes on the teacher's stream too (TeacherOut.videos is the device tensor)."""
-        from . import _lib
+    def next_slot(self, inputs_ready=None) -> int:
+        """Order this launch on the teacher's stream and return its output slot.
+        Slot reuse: launch k overwrites the outputs of launch k - n_slots, read by student step k - n_slots.  A mark recorded at launch j
+        has every student step <= j - 2 in front of it (step j - 1 is enqueued right after launch j), so the mark of launch
+        k - n_slots + 2 is late enough: the oldest of the n_slots - 1 marks kept.  With three slots the teacher may start on batch i+1
+        while the student is still on batch i-1, and neither stream waits for the other at every step (two slots: the mark of this call).
+        Inputs: ``inputs_ready`` None = unknown producer: the teacher's stream waits for everything enqueued so far on the caller's
+        stream (a device batch produced right before this call must not be read early -- round-2 advisor finding); an event = wait for
+        that; False = the caller vouches that the inputs are host memory, were produced on ``self.stream`` or are long complete."""
         slot = self.n % self.n_slots
         self.n += 1
         main = torch.cuda.current_stream()
-        # Slot reuse: launch k overwrites the outputs of launch k - n_slots, read by student step k - n_slots.  A mark recorded at launch j
-        # has every student step <= j - 2 in front of it (step j - 1 is enqueued right after launch j), so the mark of launch
-        # k - n_slots + 2 is late enough: the oldest of the n_slots - 1 marks kept.  With three slots the teacher may start on batch i+1
-        # while the student is still on batch i-1, and neither stream waits for the other at every step (two slots: the mark of this call).
         ev = torch.cuda.Event()
         ev.record(main)
         self._marks.append(ev)
         if len(self._marks) > self.n_slots - 1:
             self._marks.pop(0)
         self.stream.wait_event(self._marks[0])
-        if not videos.is_cuda:
-            self.stream.wait_event(ev)     # pinned host buffers are filled by the loader before this call; nothing else to order
+        if inputs_ready is None:
+            self.stream.wait_event(ev)
+        elif inputs_ready is not False:
+            self.stream.wait_event(inputs_ready)
+        return slot
+
+
+class TeacherAhead(AheadStream):
+    """The frozen teacher one batch ahead of the student: ``launch(videos)`` enqueues the whole teacher phase of a batch on a stream of
+    its own and returns its TeacherOut; the caller then trains the student on the PREVIOUS batch, whose teacher phase was launched an
+    iteration earlier.  Nothing in the teacher depends on the student (frozen, no_grad: run_stage1.py:371), so the arithmetic of every
+    step is that of stage1_step; what changes is that the student's many short, partially filled launches (and, on N GPUs, its gradient
+    all-reduces) share the GPU with the teacher's long GEMMs.  Outputs rotate through ``n_slots`` (three) slots.
+
+    Measured on MI355X (B = 32, DESIGN.md section 5): 23.7 -> 21.6 ms per step, 20.4 with the GEMM planner told that launches share the
+    GPU (plan_sharing: larger tiles, fewer split-K slices).  Beside a concurrent student the teacher is best left on ONE
+    stream (its three frame-range streams: +0.4 ms) and on the tile GEMM kernels (the persistent kernel keeps every CU for a whole launch,
+    so nothing of the student slips in between its tiles: +0.2 ms); UNITE_TEACHER_AHEAD_STREAMS / UNITE_TEACHER_PP change that."""
+
+    def __init__(self, teacher_model, state: StepState, device, mask_ratio, mask_type, clip_input_resolution=224):
+        super().__init__(device, int(os.environ.get("UNITE_TEACHER_AHEAD_SLOTS", "3")))
+        self.teacher, self.state = teacher_model, state
+        self.mask_ratio, self.mask_type, self.res = mask_ratio, mask_type, clip_input_resolution
+
+    def launch(self, videos, bool_masked_pos=None, importance=None, inputs_ready=None) -> TeacherOut:
+        """``videos`` may still be on the host: the copy then goes on the teacher's stream too (TeacherOut.videos is the device tensor).
+        ``inputs_ready``: see AheadStream.next_slot (default: safe for a device batch produced on the current stream just now)."""
+        slot = self.next_slot(inputs_ready)
         trt = getattr(self.teacher, "module", self.teacher).runtime()
         keep = trt.n_streams
         trt.n_streams = self.n_streams
-        lib = _lib.load()
-        policy_before = lib.unite_gemm_get_policy()
         try:
-            with torch.cuda.stream(self.stream):
-                if self.gemm_policy >= 0:
-                    lib.unite_gemm_set_policy(self.gemm_policy)      # read by the launches as they are enqueued, i.e. by this phase only
+            with torch.cuda.stream(self.stream), self.hints():
                 if not videos.is_cuda:
                     videos = videos.to(self.stream.device, non_blocking=True)
                 out = teacher_phase(self.teacher, videos, self.mask_ratio, self.mask_type, bool_masked_pos, self.state, self.res,
@@ -262,13 +273,13 @@ class TeacherAhead:
                 out.videos = videos
         finally:
             trt.n_streams = keep
-            if self.gemm_policy >= 0:
-                lib.unite_gemm_set_policy(policy_before)
         return out
 
 
 class _Ahead:
-    """iterates (batch, TeacherOut) with the teacher phase of the following batch already enqueued"""
+    """iterates (batch, TeacherOut) with the teacher phase of the following batch already enqueued.  A batch is FETCHED with the
+    teacher's stream current: whatever the loader produces on the device at that moment (synthetic clips, a device-side transform) is
+    then ordered in front of the teacher phase by the stream itself, and the student reaches it behind TeacherOut.ready."""
 
     def __init__(self, loader, prepare, ahead: TeacherAhead, mask_type):
         self.loader, self.prepare, self.ahead, self.mask_type = loader, prepare, ahead, mask_type
@@ -278,9 +289,15 @@ class _Ahead:
 
     def __iter__(self):
         prev = None
-        for batch in self.loader:
-            cur = self.prepare(batch)
-            tout = self.ahead.launch(cur[0], cur[1] if self.mask_type != 'attention' else None)
+        it = iter(self.loader)
+        while True:
+            with torch.cuda.stream(self.ahead.stream):
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    break
+                cur = self.prepare(batch)
+            tout = self.ahead.launch(cur[0], cur[1] if self.mask_type != 'attention' else None, inputs_ready=False)
             if prev is not None:
                 yield prev
             prev = (cur, tout)
@@ -362,41 +379,43 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
     else:
         source = data_loader
 
-    for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
-        it = start_steps + step
-        if lr_schedule_values is not None or wd_schedule_values is not None:
-            for param_group in optimizer.param_groups:
-                if lr_schedule_values is not None:
-                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
-                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
-                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
+    import contextlib
+    ring = getattr(loss_scaler, "RING", 256) - 2      # grad-norm results live in a ring of device slots: read them back before it wraps
+    # the student's GEMM launches carry the shared-GPU planner weight while the teacher runs ahead; left on any exit, also when the loop raises
+    with (ahead.student() if ahead_on else contextlib.nullcontext()):
+        for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
+            it = start_steps + step
+            if lr_schedule_values is not None or wd_schedule_values is not None:
+                for param_group in optimizer.param_groups:
+                    if lr_schedule_values is not None:
+                        param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
+                    if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                        param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
 
-        if ahead_on:
-            (_, bool_masked_pos, B_s), tout = item
-            videos = tout.videos
-            loss = student_phase(model, videos, tout, B_s, clip_loss_data, clip_loss_type)
-        else:
-            videos, bool_masked_pos, B_s = prepare(item)
-            loss = stage1_step(model, teacher_model, videos, B_s, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state,
-                               clip_input_resolution, clip_loss_type=clip_loss_type)
-        optimizer.zero_grad()
-        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
-        pending.append((loss, grad_norm))
+            if ahead_on:
+                (_, bool_masked_pos, B_s), tout = item
+                videos = tout.videos
+                loss = student_phase(model, videos, tout, B_s, clip_loss_data, clip_loss_type)
+            else:
+                videos, bool_masked_pos, B_s = prepare(item)
+                loss = stage1_step(model, teacher_model, videos, B_s, mask_ratio, mask_type, bool_masked_pos, clip_loss_data, state,
+                                   clip_input_resolution, clip_loss_type=clip_loss_type)
+            optimizer.zero_grad()
+            grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
+            pending.append((loss, grad_norm))
 
-        if print_freq and (step % print_freq == 0 or step == ipe - 1):
-            flush()
-        min_lr, max_lr = 10., 0.
-        for group in optimizer.param_groups:
-            min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
-        weight_decay_value = None
-        for group in optimizer.param_groups:
-            if group["weight_decay"] > 0:
-                weight_decay_value = group["weight_decay"]
-        metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
-        if lr_scheduler is not None:
-            lr_scheduler.step_update(start_steps + step)
-    if ahead_on:
-        ahead.close()
+            if (print_freq and (step % print_freq == 0 or step == ipe - 1)) or len(pending) >= ring:
+                flush()
+            min_lr, max_lr = 10., 0.
+            for group in optimizer.param_groups:
+                min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
+            weight_decay_value = None
+            for group in optimizer.param_groups:
+                if group["weight_decay"] > 0:
+                    weight_decay_value = group["weight_decay"]
+            metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
+            if lr_scheduler is not None:
+                lr_scheduler.step_update(start_steps + step)
     flush()
     metric_logger.synchronize_between_processes()
     print(f"[{time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())}] Averaged stats:", metric_logger)

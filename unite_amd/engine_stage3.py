@@ -27,7 +27,7 @@ from typing import Callable, Iterable, Optional
 import torch
 
 from . import ops, utils
-from .engine_stage1 import teacher_input
+from .engine_stage1 import AheadStream, teacher_input
 
 F32 = torch.float32
 
@@ -63,61 +63,30 @@ class MaskOut:
     __slots__ = ("cmask", "cvis", "ready", "videos_t_aug")
 
 
-class MaskTeacherAhead:
+class MaskTeacherAhead(AheadStream):
     """Stage 3's frozen mask teacher one batch ahead of the student, on a stream of its own (the stage-1 scheme, engine_stage1.TeacherAhead):
     ``launch(videos_t_aug)`` enqueues the CLIP forward + greedy masks of a batch; the caller then runs the student passes of the PREVIOUS
     batch.  The teacher's attention depends on nothing the student changes (run_stage3.py:434-451: no_grad, frozen), so every step computes
-    what stage3_step computes.  Three output slots; while it is active the GEMM planner sizes launches for a shared GPU."""
+    what stage3_step computes.  Three output slots; the GEMM launches of both sides carry the shared-GPU planner weight (hints() /
+    student()).  ``clip_probs_fn`` may run the SAME CLIP tower on the student's stream (utils.clip_infer(teacher_model, ...)): the teacher
+    runtime orders its uses across streams itself (clip._TeacherRuntime._enter / _leave)."""
 
     def __init__(self, teacher_model, student, device, mask_ratio, masking_type, clip_input_resolution):
-        from . import _lib
+        super().__init__(device, 3)
         self.teacher, self.ws = teacher_model, getattr(student, "module", student).runtime().ws
         self.N = getattr(student, "module", student).runtime().frame_tokens
         self.mask_ratio, self.masking_type, self.res = mask_ratio, masking_type, clip_input_resolution
-        self.stream = torch.cuda.Stream(device=device)
-        self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
-        self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))
-        self.n_slots, self.n, self._marks = 3, 0, []
-        lib = _lib.load()
-        self._sharing_before = lib.unite_gemm_get_sharing()
-        lib.unite_gemm_set_sharing(float(os.environ.get("UNITE_GEMM_SHARING", "0.8")))
 
-    def close(self):
-        if self._sharing_before is not None:
-            from . import _lib
-            _lib.load().unite_gemm_set_sharing(self._sharing_before)
-            self._sharing_before = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def launch(self, videos_t_aug) -> MaskOut:
-        from . import _lib
-        slot = self.n % self.n_slots
-        self.n += 1
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self._marks.append(ev)
-        if len(self._marks) > self.n_slots - 1:
-            self._marks.pop(0)
-        self.stream.wait_event(self._marks[0])      # the student step that read this slot was enqueued before that mark
-        if not videos_t_aug.is_cuda:
-            self.stream.wait_event(ev)
-        lib = _lib.load()
-        policy_before = lib.unite_gemm_get_policy()
+    def launch(self, videos_t_aug, inputs_ready=None) -> MaskOut:
+        """``inputs_ready``: see AheadStream.next_slot (default: the teacher's stream waits for everything enqueued so far on the caller's)"""
+        slot = self.next_slot(inputs_ready)
         trt = getattr(self.teacher, "module", self.teacher).runtime() if self.masking_type == "clip_attention" else None
         keep = trt.n_streams if trt is not None else None
         out = MaskOut()
         try:
             if trt is not None:
                 trt.n_streams = self.n_streams
-            with torch.cuda.stream(self.stream):
-                if self.gemm_policy >= 0:
-                    lib.unite_gemm_set_policy(self.gemm_policy)
+            with torch.cuda.stream(self.stream), self.hints():
                 if not videos_t_aug.is_cuda:
                     videos_t_aug = videos_t_aug.to(self.stream.device, non_blocking=True)
                 out.cmask, out.cvis = committee_masks(self.teacher, videos_t_aug, self.masking_type, self.mask_ratio, self.res, self.N, self.ws, slot)
@@ -127,14 +96,13 @@ class MaskTeacherAhead:
         finally:
             if trt is not None:
                 trt.n_streams = keep
-            if self.gemm_policy >= 0:
-                lib.unite_gemm_set_policy(policy_before)
         return out
 
 
 class _Stage3LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t, cfg, anchor):
+        ops.keep_plan(ctx)
         student = getattr(model, "module", model)
         rt = student.runtime()
         dev = videos_s.device
@@ -205,21 +173,22 @@ class _Stage3LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, *_):
-        student = getattr(ctx.model, "module", ctx.model)
-        rt = student.runtime()
-        ws = rt.ws
-        B_s, B_t, n_full, n_vis, D, k = ctx.dims
-        fp = rt.fp
-        if not fp.accumulate:       # clip_decoder.* gets no gradient in stage 3 (its outputs are discarded, run_stage3.py:475): keep
-            (lo, hi), = fp.layer_ranges(["clip_decoder."])      # the flat buffer's slice at zero for the grad-norm and the all-reduce
-            fp.grad[lo:hi].zero_()
-        for pi, (tag, slot, B, n, dl) in enumerate((("src", "s3src", B_s, n_full, ws.peek("s3.dlog.s")), (f"cm{k - 1}", f"s3cm{k - 1}", B_t, n_vis, ws.peek("s3.dlog.t")))):
-            dpool = ws.get(f"s3.dpool.{tag}", (B, D), F32)
-            ops.linear_f32_bwd(ws.peek(f"s3.pool.{tag}"), ctx.W, dl * gloss, dx=dpool)
-            dxv = ws.get(f"s3.dxv.{tag}", (B, n, D), F32)
-            ops.token_mean_bwd(dpool, dxv)
-            rt.encode_backward(dxv.view(B * n, D), slot, notify=pi == 1)
-        return (None,) * 10
+        with ops.kept_plan(ctx):
+            student = getattr(ctx.model, "module", ctx.model)
+            rt = student.runtime()
+            ws = rt.ws
+            B_s, B_t, n_full, n_vis, D, k = ctx.dims
+            fp = rt.fp
+            if not fp.accumulate:       # clip_decoder.* gets no gradient in stage 3 (its outputs are discarded, run_stage3.py:475): keep
+                (lo, hi), = fp.layer_ranges(["clip_decoder."])      # the flat buffer's slice at zero for the grad-norm and the all-reduce
+                fp.grad[lo:hi].zero_()
+            for pi, (tag, slot, B, n, dl) in enumerate((("src", "s3src", B_s, n_full, ws.peek("s3.dlog.s")), (f"cm{k - 1}", f"s3cm{k - 1}", B_t, n_vis, ws.peek("s3.dlog.t")))):
+                dpool = ws.get(f"s3.dpool.{tag}", (B, D), F32)
+                ops.linear_f32_bwd(ws.peek(f"s3.pool.{tag}"), ctx.W, dl * gloss, dx=dpool)
+                dxv = ws.get(f"s3.dxv.{tag}", (B, n, D), F32)
+                ops.token_mean_bwd(dpool, dxv)
+                rt.encode_backward(dxv.view(B * n, D), slot, notify=pi == 1)
+            return (None,) * 10
 
 
 def stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t, args, mask_ratio,
@@ -317,39 +286,40 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
                 yield prev
 
     source = _Ahead() if ahead_on else data_loader
-    for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
-        it = start_steps + step
-        if lr_schedule_values is not None or wd_schedule_values is not None:
-            for param_group in optimizer.param_groups:
-                if lr_schedule_values is not None:
-                    param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
-                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
-                    param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
-        (videos_s, labels_s, videos_t, videos_t_aug, labels_t), masks = item if ahead_on else (prepare(item), None)
-        videos_s, videos_t = videos_s.to(device, non_blocking=True), videos_t.to(device, non_blocking=True)
-        if masks is None:
-            videos_t_aug = videos_t_aug.to(device, non_blocking=True)
-        labels_s, labels_t = labels_s.to(device, non_blocking=True), labels_t.to(device, non_blocking=True)
+    import contextlib
+    ring = getattr(loss_scaler, "RING", 256) - 2      # grad-norm results live in a ring of device slots: read them back before it wraps
+    with (ahead.student() if ahead is not None else contextlib.nullcontext()):
+        for step, item in enumerate(metric_logger.log_every(source, print_freq, getattr(args, "epochs", None), epoch, ipe, header=header)):
+            it = start_steps + step
+            if lr_schedule_values is not None or wd_schedule_values is not None:
+                for param_group in optimizer.param_groups:
+                    if lr_schedule_values is not None:
+                        param_group["lr"] = lr_schedule_values[min(it, len(lr_schedule_values) - 1)] * param_group["lr_scale"]
+                    if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                        param_group["weight_decay"] = wd_schedule_values[min(it, len(wd_schedule_values) - 1)]
+            (videos_s, labels_s, videos_t, videos_t_aug, labels_t), masks = item if ahead_on else (prepare(item), None)
+            videos_s, videos_t = videos_s.to(device, non_blocking=True), videos_t.to(device, non_blocking=True)
+            if masks is None:
+                videos_t_aug = videos_t_aug.to(device, non_blocking=True)
+            labels_s, labels_t = labels_s.to(device, non_blocking=True), labels_t.to(device, non_blocking=True)
 
-        loss, loss_s, loss_t, sel = stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t,
-                                                args, mask_ratio, clip_probs_fn, clip_input_resolution, masks=masks)
-        optimizer.zero_grad()
-        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
-        pending.append((loss, loss_s, loss_t, sel.float().mean(), grad_norm))
-        if print_freq and (step % print_freq == 0 or step == ipe - 1):
-            flush()
-        min_lr, max_lr = 10., 0.
-        for group in optimizer.param_groups:
-            min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
-        weight_decay_value = None
-        for group in optimizer.param_groups:
-            if group["weight_decay"] > 0:
-                weight_decay_value = group["weight_decay"]
-        metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
-        if lr_scheduler is not None:
-            lr_scheduler.step_update(start_steps + step)
-    if ahead is not None:
-        ahead.close()
+            loss, loss_s, loss_t, sel = stage3_step(model, teacher_model, src_classifier, videos_s, labels_s, videos_t, videos_t_aug, labels_t,
+                                                    args, mask_ratio, clip_probs_fn, clip_input_resolution, masks=masks)
+            optimizer.zero_grad()
+            grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, reducer=reducer)
+            pending.append((loss, loss_s, loss_t, sel.float().mean(), grad_norm))
+            if (print_freq and (step % print_freq == 0 or step == ipe - 1)) or len(pending) >= ring:
+                flush()
+            min_lr, max_lr = 10., 0.
+            for group in optimizer.param_groups:
+                min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
+            weight_decay_value = None
+            for group in optimizer.param_groups:
+                if group["weight_decay"] > 0:
+                    weight_decay_value = group["weight_decay"]
+            metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
+            if lr_scheduler is not None:
+                lr_scheduler.step_update(start_steps + step)
     flush()
     metric_logger.synchronize_between_processes()
     print(f"[{time.strftime('%Y-%m-%d %H:%M:%S', time.localtime())}] Averaged stats:", metric_logger)

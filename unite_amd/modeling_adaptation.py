@@ -504,6 +504,7 @@ class _StudentFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, videos, vis_tokens, n_vis, clip_only, anchor):
+        ops.keep_plan(ctx)
         rt = model.runtime()
         ys, xs = rt.forward_features(videos, vis_tokens, n_vis, clip_only, model.training)
         B, M, C, K = videos.shape[0], videos.shape[0] * n_vis, rt.C, len(rt.taps)
@@ -521,27 +522,28 @@ class _StudentFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        model = ctx.model
-        rt = model.runtime()
-        c = rt._ctx
-        M, C = c["M"], rt.C
-        dout = grads[0] if ctx.clip_only else grads[1]
-        dxv = None if ctx.clip_only else grads[0]
-        dout_c = None if dout is None else dout.contiguous()
-        acc = rt.fp.accumulate
+        with ops.kept_plan(ctx):
+            model = ctx.model
+            rt = model.runtime()
+            c = rt._ctx
+            M, C = c["M"], rt.C
+            dout = grads[0] if ctx.clip_only else grads[1]
+            dxv = None if ctx.clip_only else grads[0]
+            dout_c = None if dout is None else dout.contiguous()
+            acc = rt.fp.accumulate
 
-        def tail_bwd(k, lnws):
-            d = rt.dec[k]
-            dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
-            if dout_c is None:
-                dy.zero_()
-            else:
-                ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout_c[k].view(M, C), dy,
-                                     d["gnw"], d["gnb"], lnws, accumulate=acc, dysum=d["gb"])
-            return dy
+            def tail_bwd(k, lnws):
+                d = rt.dec[k]
+                dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
+                if dout_c is None:
+                    dy.zero_()
+                else:
+                    ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, None, 0.0, dout_c[k].view(M, C), dy,
+                                         d["gnw"], d["gnb"], lnws, accumulate=acc, dysum=d["gb"])
+                return dy
 
-        rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D), tail_bwd=tail_bwd)
-        return None, None, None, None, None, None
+            rt.backward_from_dy(None if dxv is None else dxv.contiguous().view(M, rt.D), tail_bwd=tail_bwd)
+            return None, None, None, None, None, None
 
 
 class _StudentLossFn(torch.autograd.Function):
@@ -549,6 +551,7 @@ class _StudentLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, videos, vis_tokens, n_vis, targets, anchor):
+        ops.keep_plan(ctx)
         rt = model.runtime()
         M, C, K = videos.shape[0] * n_vis, rt.C, len(rt.taps)
         loss_sum = rt.ws.get("loss.sum", (1,), F32)
@@ -573,22 +576,23 @@ class _StudentLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss):
-        model = ctx.model
-        rt = model.runtime()
-        c = rt._ctx
-        M, C, K = c["M"], rt.C, len(rt.taps)
-        g = gloss.contiguous().to(F32)
-        acc, targets = rt.fp.accumulate, ctx.targets
+        with ops.kept_plan(ctx):
+            model = ctx.model
+            rt = model.runtime()
+            c = rt._ctx
+            M, C, K = c["M"], rt.C, len(rt.taps)
+            g = gloss.contiguous().to(F32)
+            acc, targets = rt.fp.accumulate, ctx.targets
 
-        def tail_bwd(k, lnws):
-            d = rt.dec[k]
-            dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
-            ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, targets[k], 1.0 / float(K * M), None, dy,
-                                 d["gnw"], d["gnb"], lnws, accumulate=acc, loss_scale_dev=g, dysum=d["gb"])
-            return dy
+            def tail_bwd(k, lnws):
+                d = rt.dec[k]
+                dy = rt.ws.get(f"dec.dy{k}", (M, C), BF16)
+                ops.decoder_tail_bwd(rt._tap[k]["y"], d["nw"], d["nb"], model.ln_eps, targets[k], 1.0 / float(K * M), None, dy,
+                                     d["gnw"], d["gnb"], lnws, accumulate=acc, loss_scale_dev=g, dysum=d["gb"])
+                return dy
 
-        rt.backward_from_dy(None, tail_bwd=tail_bwd)
-        return None, None, None, None, None, None
+            rt.backward_from_dy(None, tail_bwd=tail_bwd)
+            return None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- factories (reference :337-378)

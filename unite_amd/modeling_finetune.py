@@ -190,18 +190,21 @@ class _VitRuntime:
 class _VitFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, videos, anchor):
+        ops.keep_plan(ctx)
         ctx.model = model
         return model.runtime().forward_logits(videos, model.training)
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.model.runtime().backward_from_dlogits(dlogits.contiguous().to(F32))
-        return None, None, None
+        with ops.kept_plan(ctx):
+            ctx.model.runtime().backward_from_dlogits(dlogits.contiguous().to(F32))
+            return None, None, None
 
 
 class _VitLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, videos, targets, loss_scale, anchor):
+        ops.keep_plan(ctx)
         rt = model.runtime()
         logits = rt.forward_logits(videos, model.training)
         B = logits.shape[0]
@@ -215,10 +218,11 @@ class _VitLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
-        rt = ctx.model.runtime()
-        dlog = rt.ws.bufs["cls.dlogits"]
-        rt.backward_from_dlogits(dlog * gloss)          # gloss is 1 unless the caller scaled the loss again
-        return None, None, None, None, None
+        with ops.kept_plan(ctx):
+            rt = ctx.model.runtime()
+            dlog = rt.ws.bufs["cls.dlogits"]
+            rt.backward_from_dlogits(dlog * gloss)          # gloss is 1 unless the caller scaled the loss again
+            return None, None, None, None, None
 
 
 def _factory(embed_dim, depth, num_heads, img_size=224, **kwargs):

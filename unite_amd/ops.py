@@ -3,7 +3,9 @@ stream; every device op below is a hand-written gfx950 kernel in libunite_hip.so
 CPU fallback, a CPU tensor raises."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -52,17 +54,78 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
 
 
+class _PlanHints(threading.local):
+    """per-thread GEMM planner hints that travel INSIDE each unite_gemm_args (plan_flags / plan_persistent / plan_sharing): no process
+    global is written, so two host threads -- or a non-Python binder beside this one -- never see each other's choice"""
+    persistent: Optional[int] = None
+    sharing: Optional[float] = None
+
+
+_hints = _PlanHints()
+
+
+@contextlib.contextmanager
+def plan(persistent: Optional[int] = None, sharing: Optional[float] = None):
+    """GEMM launches enqueued inside the block carry these hints (None: leave as is): ``persistent`` as unite_gemm_set_policy
+    (0 never / 1 measured shapes / 2 whenever supported), ``sharing`` as unite_gemm_set_sharing (0 .. 1: how much the launch's CU time
+    counts against its latency -- the launches share the GPU with another stream)."""
+    before = (_hints.persistent, _hints.sharing)
+    if persistent is not None:
+        _hints.persistent = int(persistent)
+    if sharing is not None:
+        _hints.sharing = float(sharing)
+    try:
+        yield
+    finally:
+        _hints.persistent, _hints.sharing = before
+
+
+def keep_plan(ctx) -> None:
+    """autograd.Function.forward: remember the hints in force (the backward runs on the autograd engine's own thread, where this
+    thread's hints are not visible)"""
+    ctx._unite_plan = (_hints.persistent, _hints.sharing)
+
+
+@contextlib.contextmanager
+def kept_plan(ctx):
+    """autograd.Function.backward: the launches of the backward carry the hints its forward ran under"""
+    before = (_hints.persistent, _hints.sharing)
+    _hints.persistent, _hints.sharing = getattr(ctx, "_unite_plan", before)
+    try:
+        yield
+    finally:
+        _hints.persistent, _hints.sharing = before
+
+
+def prepare_workspace(workspace: torch.Tensor) -> torch.Tensor:
+    """GEMM workspaces start with UNITE_WS_HEADER_BYTES of arrival counters that must be zero before the first launch (every launch
+    leaves them zero): zeroed once per tensor object."""
+    if not getattr(workspace, "_unite_ws_ready", False):
+        workspace.view(torch.uint8).view(-1)[:min(_lib.WS_HEADER_BYTES, workspace.numel() * workspace.element_size())].zero_()
+        workspace._unite_ws_ready = True
+    return workspace
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
          aux_out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 1,
          residual: Optional[torch.Tensor] = None, accumulate: bool = False,
          out_bf16_copy: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-         colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False) -> torch.Tensor:
+         colsum_out: Optional[torch.Tensor] = None, colsum_accumulate: bool = False,
+         rowsum_out: Optional[torch.Tensor] = None, rowsum_accumulate: bool = False, rowsum_zero_range=(0, 0)) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)); a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views.
-    colsum_out (f32 [N]) (+)= column sums of the stored out (needs workspace >= gemm_colsum_workspace(M, N) bytes)."""
+    residual: f32 or bf16 [M,N].  colsum_out (f32 [N]) (+)= column sums of the stored out (needs workspace >= gemm_colsum_workspace(M, N)
+    bytes).  rowsum_out (f32 [M]) (+)= row sums of op(a) (the bias gradient when the product is a weight gradient dY^T X); rows in
+    rowsum_zero_range are written as zeros."""
     lib = _lib.load()
     g = _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scale, rows_per_scale, residual, accumulate,
                    out_bf16_copy, workspace)
+    if rowsum_out is not None:
+        _req(rowsum_out, F32, "rowsum_out")
+        if rowsum_out.numel() != out.shape[0]:
+            raise ValueError("rowsum_out must have M elements")
+        g.rowsum_a_out, g.rowsum_accumulate = _ptr(rowsum_out), int(rowsum_accumulate)
+        g.rowsum_zero_lo, g.rowsum_zero_hi = int(rowsum_zero_range[0]), int(rowsum_zero_range[1])
     if colsum_out is not None:
         _req(colsum_out, F32, "colsum_out")
         if colsum_out.numel() != out.shape[1]:
@@ -112,22 +175,37 @@ def _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scal
     g.aux_in, g.ld_aux_in = _ptr(aux_in), (aux_in.stride(0) if aux_in is not None else 0)
     g.aux_out, g.ld_aux_out = _ptr(aux_out), (aux_out.stride(0) if aux_out is not None else 0)
     g.row_scale, g.rows_per_scale = _ptr(row_scale), rows_per_scale
-    if residual is not None:
-        _req(residual, F32, "residual")
+    if residual is not None and residual.dtype not in (F32, BF16):
+        raise TypeError("residual must be f32 or bf16")
     g.residual, g.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
+    g.residual_bf16 = int(residual is not None and residual.dtype == BF16)
     if out.dtype not in (BF16, F32):
         raise TypeError("out must be bf16 or f32")
     g.out, g.ldc, g.out_f32, g.accumulate = _ptr(out), out.stride(0), int(out.dtype == F32), int(accumulate)
     g.out_bf16_copy, g.ld_copy = _ptr(out_bf16_copy), (out_bf16_copy.stride(0) if out_bf16_copy is not None else 0)
+    if workspace is not None:
+        prepare_workspace(workspace)
     g.workspace, g.workspace_bytes = _ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
+    if _hints.persistent is not None:
+        g.plan_flags |= 1
+        g.plan_persistent = _hints.persistent
+    if _hints.sharing is not None:
+        g.plan_flags |= 2
+        g.plan_sharing = _hints.sharing
     return g
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, y: torch.Tensor, *, row_index=None, post_add=None,
                   mean=None, rstd=None) -> torch.Tensor:
     lib = _lib.load()
-    _req(x, F32, "x")
     M, D = y.shape
+    if x.dtype == BF16:          # the teacher's bf16 residual stream
+        _req(x, BF16, "x")
+        _lib.check(lib.unite_layernorm_fwd_bf16in(_ptr(x), x.stride(0), _ptr(row_index), _ptr(gamma), _ptr(beta), eps, _ptr(post_add),
+                                                  _ptr(y), int(y.dtype == F32), _ptr(mean), _ptr(rstd), M, D, _stream()),
+                   "unite_layernorm_fwd_bf16in")
+        return y
+    _req(x, F32, "x")
     _lib.check(lib.unite_layernorm_fwd(_ptr(x), x.stride(0), _ptr(row_index), _ptr(gamma), _ptr(beta), eps, _ptr(post_add),
                                        _ptr(y), int(y.dtype == F32), _ptr(mean), _ptr(rstd), M, D, _stream()),
                "unite_layernorm_fwd")
@@ -157,6 +235,7 @@ def colsum(x: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, accumula
     lib = _lib.load()
     _req(x, BF16, "x")
     M, N = x.shape
+    prepare_workspace(workspace)
     _lib.check(lib.unite_colsum_bf16(_ptr(x), x.stride(0), M, N, _ptr(out), int(accumulate), zero_range[0], zero_range[1],
                                      _ptr(workspace), _stream()),
                "unite_colsum_bf16")
@@ -259,7 +338,8 @@ def gather_rows(table, index, out, modulo: int = 0):
 
 def clip_embed_ln(patches, cls, pos, gamma, beta, eps: float, x, BT: int, HW: int, D: int):
     lib = _lib.load()
-    _lib.check(lib.unite_clip_embed_ln(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), eps, _ptr(x), BT, HW, D, _stream()),
+    _lib.check(lib.unite_clip_embed_ln(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), eps, _ptr(x), int(x.dtype == F32), BT, HW, D,
+                                       _stream()),
                "unite_clip_embed_ln")
     return x
 

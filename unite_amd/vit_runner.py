@@ -22,7 +22,8 @@ from . import ops
 from .flat_params import FlatParams
 
 BF16, F32 = torch.bfloat16, torch.float32
-SPLITK_WS_BYTES = 16 * 3072 * 1024 * 4      # split-K slabs of the weight-gradient GEMMs: up to 16 slices of a 3072 x 1024 f32 tile
+# workspace of the weight-gradient GEMMs: arrival counters + per-slice bias row sums + up to 16 split-K slabs of a 3072 x 1024 f32 output
+SPLITK_WS_BYTES = 32768 + 16 * 4096 * 4 + 16 * 3072 * 1024 * 4
 
 
 class Workspace:
@@ -223,10 +224,8 @@ class ViTRunner:
         M = B * N
         acc = fp.accumulate
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
-        csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(Hd, 3 * D)))
         nside = self.wgrad_streams if (dx.is_cuda and self.wgrad_stream) else 1
         gws_k = [ws.bytes_("gemm.ws" if k == 0 else f"gemm.ws.{k}", SPLITK_WS_BYTES) for k in range(nside)]      # split-K slabs: one set per stream
-        csws_k = [csws if k == 0 else ws.bytes_(f"cs.ws.{k}", ops.colsum_workspace(M, max(Hd, 3 * D))) for k in range(nside)]
         gcws = ws.bytes_("gemm.cs.ws", ops.gemm_colsum_workspace(M, Hd))
         # Weight-gradient GEMMs and bias column sums are off the critical path (nothing in the backward chain reads them): they
         # run on a side HIP stream behind events, concurrently with the next dgrad GEMM / LayerNorm backward / attention backward
@@ -293,9 +292,12 @@ class ViTRunner:
                 ops.gemm(dxb, s["a"], w["g:mlp.fc2.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
 
             def fc1_wgrad(k, dz=dz, w=w, s=s):
-                ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
-                if not self.fused_colsum:
-                    ops.colsum(dz, w["g:mlp.fc1.bias"], csws_k[k], accumulate=acc)
+                # the fc1 bias gradient = column sums of dz = row sums of this product's A operand (dz^T): taken from the A tiles in LDS
+                if self.fused_colsum:
+                    ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+                else:
+                    ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k],
+                             rowsum_out=w["g:mlp.fc1.bias"], rowsum_accumulate=acc)
             on_side(fc2_wgrad, 0, i)
             on_side(fc1_wgrad, 1, i)
             dh2 = ws.get("bw.dh", (M, D), BF16)
@@ -318,8 +320,8 @@ class ViTRunner:
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
 
             def qkv_wgrads(k, dqkv=dqkv, w=w, s=s):
-                ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
-                ops.colsum(dqkv, w["g:qkv_bias"], csws_k[k], accumulate=acc, zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
+                ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k],
+                         rowsum_out=w["g:qkv_bias"], rowsum_accumulate=acc, rowsum_zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
             on_side(qkv_wgrads, 3, i)
             # gradient w.r.t. this block's input; its bf16 copy feeds block i-1's MLP branch (scaled by that
             # branch's drop-path factor) or the patch-embed weight gradient (unscaled)
@@ -346,6 +348,5 @@ class ViTRunner:
         ws, fp, D = self.ws, self.fp, self.D
         cols = ws.peek("pe.cols")
         M = cols.shape[0]
-        csws = ws.bytes_("cs.ws", ops.colsum_workspace(M, max(self.Hd, 3 * D)))
         ops.gemm(dxb, cols, self._pe_gw.view(D, -1), trans_a=True, trans_b=True, accumulate=fp.accumulate,
                  workspace=ws.bytes_("gemm.ws", SPLITK_WS_BYTES))      # the bias gradient came with dxb (blocks_backward)
