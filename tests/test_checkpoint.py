@@ -171,3 +171,36 @@ def test_read_checkpoint_refuses_pickles_without_opt_in(tmp_path, monkeypatch):
     monkeypatch.delenv("UNITE_UNSAFE_CHECKPOINT_LOAD", raising=False)
     with pytest.raises(RuntimeError, match="UNITE_UNSAFE_CHECKPOINT_LOAD"):
         read_checkpoint(str(bad))
+
+
+def test_stage2_hand_off_vs_reference_golden(golden_dir, tmp_path):
+    """checkpoint.load_from_ckpt against the reference's OWN load_from_ckpt (run_stage2.py:349-438 executed from its syntax tree by
+    oracle/make_golden_posembed.py): model-key selection, the 710 -> 400 head rows / --delete_head, 'encoder.' / 'backbone.' prefix stripping
+    and the position table -- linear in time then bicubic in space, class token kept -- on three small checkpoints."""
+    import json
+    from collections import OrderedDict
+    from types import SimpleNamespace
+    import numpy as np
+    from unite_amd import checkpoint, utils
+    z = np.load(os.path.join(golden_dir, "stage2_ckpt.npz"))
+    for tag in ("a", "b", "c"):
+        c = json.loads(str(z[f"{tag}.in.cfg"]))
+        sd = OrderedDict((k[len(tag) + 4:], torch.from_numpy(z[k])) for k in z.files if k.startswith(f"{tag}.in.") and not k.endswith(".cfg"))
+        path = str(tmp_path / f"{tag}.pth")
+        torch.save({c["key"]: sd} if c["key"] else sd, path)
+        n_new = c["t_new"] * c["s_new"] ** 2
+        model = SimpleNamespace(patch_embed=SimpleNamespace(num_patches=n_new, tubelet_size=1), pos_embed=torch.zeros(1, n_new + c["extra"], 16))
+        args = SimpleNamespace(finetune=path, model_key="model|module", delete_head=c["delete_head"], nb_classes=c["nb"], num_frames=c["t_new"],
+                               model_prefix="")
+        got = {}
+        keep = utils.load_state_dict
+        utils.load_state_dict = lambda m, d, prefix='': got.update(sd=d)
+        try:
+            checkpoint.load_from_ckpt(args, model)
+        finally:
+            utils.load_state_dict = keep
+        assert list(got["sd"].keys()) == [str(k) for k in z[f"{tag}.out.keys"]], tag
+        for k, v in got["sd"].items():
+            ref = torch.from_numpy(z[f"{tag}.out.{k}"])
+            assert v.shape == ref.shape, (tag, k)
+            torch.testing.assert_close(v, ref, atol=1e-6, rtol=1e-6)

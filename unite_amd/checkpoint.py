@@ -30,10 +30,11 @@ def read_checkpoint(path: str, trusted: bool = False):
     import os
     if str(path).startswith("https"):
         raise RuntimeError("remote checkpoints are not fetched (no network in this build); download the file and pass its path")
+    import pickle
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:
+    except pickle.UnpicklingError as e:      # the tensor-only loader's refusal; a missing / unreadable / corrupt file raises what it raises
         if not (trusted or os.environ.get("UNITE_UNSAFE_CHECKPOINT_LOAD", "0") == "1"):
             raise RuntimeError(
                 f"{path}: refused by the tensor-only loader ({type(e).__name__}: {str(e).splitlines()[0][:200]}).  If you trust the file, "
@@ -51,39 +52,46 @@ def _select(checkpoint, model_key: str):
     return checkpoint, False
 
 
+def _resize_time(grid: torch.Tensor, frames: int) -> torch.Tensor:
+    """(t, s, s, C) position grid -> (frames, s, s, C): linear along the frame axis, one 1-D signal per (cell, channel)"""
+    t, s, _, C = grid.shape
+    lines = grid.reshape(t, s * s * C).t().unsqueeze(0)                                   # (1, cells x channels, t)
+    lines = torch.nn.functional.interpolate(lines, size=frames, mode='linear')
+    return lines.squeeze(0).t().reshape(frames, s, s, C)
+
+
+def _resize_space(grid: torch.Tensor, side: int) -> torch.Tensor:
+    """(t, s, s, C) position grid -> (t, side, side, C): bicubic inside every frame"""
+    planes = torch.nn.functional.interpolate(grid.permute(0, 3, 1, 2), size=(side, side), mode='bicubic', align_corners=False)
+    return planes.permute(0, 2, 3, 1)
+
+
 def interpolate_pos_embed(checkpoint_model, model, num_frames: int, patch_embed=None, pretrain_frames: int = 8):
-    """run_stage1.py:553-591 == run_stage2.py:396-434 == run_stage3.py:875-913: linear in time (the checkpoints were pre-trained
-    on 8 frames), then bicubic in space; class / dist tokens are kept.  In place on checkpoint_model['pos_embed']."""
-    if 'pos_embed' not in checkpoint_model:
+    """The position table of a checkpoint fitted to ``model``'s token grid, as the reference does it in run_stage1.py:553-591 ==
+    run_stage2.py:396-434 == run_stage3.py:875-913: the checkpoints were pre-trained on ``pretrain_frames`` frames, so the table is a
+    (frames, side, side) grid behind the class / dist tokens; it is resized linearly along the frame axis first and bicubically
+    inside every frame second, the extra tokens are kept.  In place on checkpoint_model['pos_embed'] (tests/golden/stage2_ckpt.npz:
+    the reference's own load_from_ckpt on the same files).  With extra tokens the reference's frame resize reshapes them INTO the
+    grid and fails; here they are set aside first."""
+    table = checkpoint_model.get('pos_embed')
+    if table is None:
         return checkpoint_model
     pe = patch_embed if patch_embed is not None else model.patch_embed
-    pos_embed_checkpoint = checkpoint_model['pos_embed']
-    embedding_size = pos_embed_checkpoint.shape[-1]
-    num_patches = pe.num_patches
-    num_extra_tokens = model.pos_embed.shape[-2] - num_patches
-    orig_t_size = pretrain_frames // pe.tubelet_size
-    new_t_size = num_frames // pe.tubelet_size
-    orig_size = int(((pos_embed_checkpoint.shape[-2] - num_extra_tokens) // orig_t_size) ** 0.5)
-    new_size = int((num_patches // new_t_size) ** 0.5)
-    if orig_t_size != new_t_size:
-        print(f"Temporal interpolate from {orig_t_size} to {new_t_size}")
-        tmp = pos_embed_checkpoint.view(1, orig_t_size, -1, embedding_size)
-        tmp = tmp.permute(0, 2, 3, 1).reshape(-1, embedding_size, orig_t_size)
-        tmp = torch.nn.functional.interpolate(tmp, size=new_t_size, mode='linear')
-        tmp = tmp.view(1, -1, embedding_size, new_t_size)
-        tmp = tmp.permute(0, 3, 1, 2).reshape(1, -1, embedding_size)
-        checkpoint_model['pos_embed'] = tmp
-        pos_embed_checkpoint = tmp
-    if orig_size != new_size:
-        print("Position interpolate from %dx%d to %dx%d" % (orig_size, orig_size, new_size, new_size))
-        extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
-        pos_tokens = pos_embed_checkpoint[:, num_extra_tokens:]
-        pos_tokens = pos_tokens.reshape(-1, new_t_size, orig_size, orig_size, embedding_size)
-        pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
-        pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size), mode='bicubic', align_corners=False)
-        pos_tokens = pos_tokens.permute(0, 2, 3, 1).reshape(-1, new_t_size, new_size, new_size, embedding_size)
-        pos_tokens = pos_tokens.flatten(1, 3)
-        checkpoint_model['pos_embed'] = torch.cat((extra_tokens, pos_tokens), dim=1)
+    C = table.shape[-1]
+    n_extra = model.pos_embed.shape[-2] - pe.num_patches
+    t_old, t_new = pretrain_frames // pe.tubelet_size, num_frames // pe.tubelet_size
+    s_old = int(((table.shape[-2] - n_extra) // t_old) ** 0.5)
+    s_new = int((pe.num_patches // t_new) ** 0.5)
+    if (t_old, s_old) == (t_new, s_new):
+        return checkpoint_model
+    extra, grid = table[0, :n_extra], table[0, n_extra:].reshape(t_old, s_old, s_old, C)
+    if t_old != t_new:
+        print(f"Temporal interpolate from {t_old} to {t_new}")
+        grid = _resize_time(grid, t_new)
+    if s_old != s_new:
+        print("Position interpolate from %dx%d to %dx%d" % (s_old, s_old, s_new, s_new))
+        grid = _resize_space(grid, s_new)
+    checkpoint_model['pos_embed'] = torch.cat((extra, grid.reshape(-1, C)), dim=0).unsqueeze(0)
     return checkpoint_model
 
 
@@ -140,27 +148,39 @@ def load_student_from_ckpt_stage3(args, model):
     return _finish_student(args, model, _strip_backbone(checkpoint_model, strip_encoder=False))
 
 
+def _fit_head(sd, args):
+    """the classifier rows of a pre-trained checkpoint against this run's classes (run_stage2.py:366-382): dropped on --delete_head; a
+    Kinetics-710 head keeps its first 400 rows for K400 or the rows a label map names for K600 / K700; anything else is left alone (a
+    shape mismatch is then reported and skipped by utils.load_state_dict)"""
+    if 'head.weight' not in sd:
+        return
+    if getattr(args, "delete_head", False):
+        print("Removing head from pretrained checkpoint")
+        rows = None
+    elif sd['head.weight'].shape[0] != 710:
+        return
+    elif args.nb_classes == 400:
+        rows = slice(0, 400)
+    elif args.nb_classes in (600, 700):
+        map_path = f'k710/label_mixto{args.nb_classes}.json'
+        print(f'Load label map from {map_path}')
+        with open(map_path) as f:
+            rows = json.load(f)
+    else:
+        return
+    for key in ('head.weight', 'head.bias'):
+        if rows is None:
+            del sd[key]
+        else:
+            sd[key] = sd[key][rows]
+
+
 def load_from_ckpt(args, model):
     """run_stage2.py:349-438: classifier initialisation from a pre-trained / stage-1 checkpoint."""
     checkpoint = read_checkpoint(args.finetune)
     print("Load ckpt from %s" % args.finetune)
     checkpoint_model, _ = _select(checkpoint, args.model_key)
-    if 'head.weight' in checkpoint_model.keys():
-        if getattr(args, "delete_head", False):
-            print("Removing head from pretrained checkpoint")
-            del checkpoint_model['head.weight']
-            del checkpoint_model['head.bias']
-        elif checkpoint_model['head.weight'].shape[0] == 710:
-            if args.nb_classes == 400:
-                checkpoint_model['head.weight'] = checkpoint_model['head.weight'][:args.nb_classes]
-                checkpoint_model['head.bias'] = checkpoint_model['head.bias'][:args.nb_classes]
-            elif args.nb_classes in [600, 700]:
-                map_path = f'k710/label_mixto{args.nb_classes}.json'
-                print(f'Load label map from {map_path}')
-                with open(map_path) as f:
-                    label_map = json.load(f)
-                checkpoint_model['head.weight'] = checkpoint_model['head.weight'][label_map]
-                checkpoint_model['head.bias'] = checkpoint_model['head.bias'][label_map]
+    _fit_head(checkpoint_model, args)
     checkpoint_model = _strip_backbone(checkpoint_model, strip_encoder=True)
     if 'pos_embed' in checkpoint_model and hasattr(model, "pos_embed"):
         interpolate_pos_embed(checkpoint_model, model, args.num_frames)

@@ -138,119 +138,145 @@ def _gather_all(t):
     return torch.cat(parts)
 
 
+class _EvalPass:
+    """One pass of a classifier over a loader without gradients: what ``validation_one_epoch`` (engine_for_finetuning.py:174-232) and
+    ``final_test`` (:235-296) have in common -- logits per batch, cross-entropy / top-1 / top-5 meters weighted by batch size, the soft-max
+    rows and labels kept for the calibration error -- with a hook per batch for what differs (the per-view lines of final_test)."""
+
+    def __init__(self, model, device, header):
+        self.model, self.device, self.header = model, device, header
+        self.criterion = torch.nn.CrossEntropyLoss()
+        self.meters = utils.MetricLogger(delimiter="  ")
+        self.probs, self.labels = [], []
+        self.last_acc = (torch.zeros(()), torch.zeros(()))
+
+    def run(self, data_loader, per_batch=None):
+        self.model.eval()
+        for batch in self.meters.log_every(data_loader, 10, 1, 0, len(data_loader), header=self.header):
+            videos = batch[0].to(self.device, non_blocking=True)
+            target = batch[1].to(self.device, non_blocking=True)
+            logits = self.model(videos)
+            n = videos.shape[0]
+            self.last_acc = accuracy(logits, target, topk=(1, 5))
+            self.meters.update(loss=self.criterion(logits, target).item())
+            self.meters.meters['acc1'].update(self.last_acc[0].item(), n=n)
+            self.meters.meters['acc5'].update(self.last_acc[1].item(), n=n)
+            self.probs.append(torch.softmax(logits, dim=1))
+            self.labels.append(target)
+            if per_batch is not None:
+                per_batch(batch, logits, target)
+        return self
+
+    def calibration(self, gather: bool):
+        probs, labels = torch.cat(self.probs), torch.cat(self.labels)
+        if gather:
+            probs, labels = _gather_all(probs), _gather_all(labels)
+        ece = compute_ece(probs.cpu(), labels.cpu())
+        print(f"Expected Calibration Error (ECE): {ece:.4f}")
+        return ece, probs, labels
+
+    def summary(self):
+        self.meters.synchronize_between_processes()
+        m = self.meters
+        print('* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}'.format(top1=m.acc1, top5=m.acc5, losses=m.loss))
+        return {k: meter.global_avg for k, meter in m.meters.items()}
+
+
 @torch.no_grad()
 def validation_one_epoch(data_loader, model, device, fp32=False, save_preds_path=None):
-    """engine_for_finetuning.py:174-232: loss / top-1 / top-5 over the loader, ECE over the gathered soft-max outputs."""
+    """engine_for_finetuning.py:174-232: loss / top-1 / top-5 over the loader, ECE over the soft-max outputs gathered from all ranks;
+    optionally the predictions and labels as .npy files."""
     import os
     import numpy as np
-    criterion = torch.nn.CrossEntropyLoss()
-    metric_logger = utils.MetricLogger(delimiter="  ")
-    header = 'Val:'
-    ipe = len(data_loader)
-    model.eval()
-    softmaxes, labels = [], []
-    for batch in metric_logger.log_every(data_loader, 10, 1, 0, ipe, header=header):
-        videos = batch[0].to(device, non_blocking=True)
-        target = batch[1].to(device, non_blocking=True)
-        output = model(videos)
-        loss = criterion(output, target)
-        acc1, acc5 = accuracy(output, target, topk=(1, 5))
-        batch_size = videos.shape[0]
-        metric_logger.update(loss=loss.item())
-        metric_logger.meters['acc1'].update(acc1.item(), n=batch_size)
-        metric_logger.meters['acc5'].update(acc5.item(), n=batch_size)
-        softmaxes.append(torch.softmax(output, dim=1))
-        labels.append(target)
-    softmaxes = _gather_all(torch.cat(softmaxes))
-    labels = _gather_all(torch.cat(labels))
-    ece = compute_ece(softmaxes.cpu(), labels.cpu())
-    print(f"Expected Calibration Error (ECE): {ece:.4f}")
+    ev = _EvalPass(model, device, 'Val:').run(data_loader)
+    ece, probs, labels = ev.calibration(gather=True)
     if save_preds_path is not None:
         os.makedirs(save_preds_path, exist_ok=True)
-        np.save(os.path.join(save_preds_path, 'preds.npy'), torch.argmax(softmaxes, dim=1).cpu().numpy())
+        np.save(os.path.join(save_preds_path, 'preds.npy'), torch.argmax(probs, dim=1).cpu().numpy())
         np.save(os.path.join(save_preds_path, 'labels.npy'), labels.cpu().numpy())
         print(f"Saved predictions to {save_preds_path}")
-    metric_logger.synchronize_between_processes()
-    print('* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}'
-          .format(top1=metric_logger.acc1, top5=metric_logger.acc5, losses=metric_logger.loss))
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}, ece
+    return ev.summary(), ece
+
+
+def view_line(video_id, logits_row, label, chunk, split) -> str:
+    """one line of a rank's result file: '<id> [l0, l1, ...] <label> <chunk> <split>' (the format ``merge`` parses; :270-275)"""
+    return "{} {} {} {} {}\n".format(video_id, str(logits_row.numpy().tolist()), str(int(label)), str(int(chunk)), str(int(split)))
 
 
 @torch.no_grad()
 def final_test(data_loader, model, device, file):
-    """engine_for_finetuning.py:235-296: per-view logits written as '<id> [logits] <label> <chunk> <split>' lines (first line: the
-    last batch's acc1, acc5, as in the reference) for ``merge``."""
-    criterion = torch.nn.CrossEntropyLoss()
-    metric_logger = utils.MetricLogger(delimiter="  ")
-    header = 'Test:'
-    model.eval()
-    final_result, softmaxes, labels = [], [], []
-    acc1 = acc5 = torch.zeros(())
-    for batch in metric_logger.log_every(data_loader, 10, 1, 0, len(data_loader), header):
-        videos, target, ids, chunk_nb, split_nb = batch[0], batch[1], batch[2], batch[3], batch[4]
-        videos = videos.to(device, non_blocking=True)
-        target = target.to(device, non_blocking=True)
-        output = model(videos)
-        loss = criterion(output, target)
-        out_cpu, tgt_cpu = output.cpu(), target.cpu()
-        for i in range(output.size(0)):
-            final_result.append("{} {} {} {} {}\n".format(ids[i], str(out_cpu[i].numpy().tolist()), str(int(tgt_cpu[i])),
-                                                          str(int(chunk_nb[i])), str(int(split_nb[i]))))
-        acc1, acc5 = accuracy(output, target, topk=(1, 5))
-        batch_size = videos.shape[0]
-        metric_logger.update(loss=loss.item())
-        metric_logger.meters['acc1'].update(acc1.item(), n=batch_size)
-        metric_logger.meters['acc5'].update(acc5.item(), n=batch_size)
-        softmaxes.append(torch.softmax(output, dim=1).cpu())
-        labels.append(tgt_cpu)
-    ece = compute_ece(torch.cat(softmaxes), torch.cat(labels))
-    print(f"Expected Calibration Error (ECE): {ece:.4f}")
+    """engine_for_finetuning.py:235-296: every (video, temporal chunk, spatial crop) view's logits go to ``file`` for ``merge``; its first
+    line carries the LAST batch's acc1, acc5 (as the reference writes it)."""
+    lines = []
+
+    def keep_views(batch, logits, target):
+        ids, chunk_nb, split_nb = batch[2], batch[3], batch[4]
+        rows, tgt = logits.cpu(), target.cpu()
+        lines.extend(view_line(ids[i], rows[i], tgt[i], chunk_nb[i], split_nb[i]) for i in range(rows.size(0)))
+
+    ev = _EvalPass(model, device, 'Test:').run(data_loader, per_batch=keep_views)
+    ece, _, _ = ev.calibration(gather=False)
     with open(file, 'w') as f:
-        f.write("{}, {}\n".format(acc1, acc5))
-        for line in final_result:
-            f.write(line)
-    metric_logger.synchronize_between_processes()
-    print('* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}'
-          .format(top1=metric_logger.acc1, top5=metric_logger.acc5, losses=metric_logger.loss))
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}, ece
+        f.write("{}, {}\n".format(*ev.last_acc))
+        f.writelines(lines)
+    return ev.summary(), ece
 
 
 def compute_video(lst):
-    """engine_for_finetuning.py:344-352: mean of the per-view soft-max vectors -> prediction, top-1 / top-5 hits."""
+    """engine_for_finetuning.py:344-352 (``[index, video_id, per-view soft-max vectors, label]``): the video's score is the mean over
+    its views -> [prediction, top-1 hit, top-5 hit, label]."""
     import numpy as np
-    i, video_id, data, label = lst
-    feat = np.mean([x for x in data], axis=0)
-    pred = np.argmax(feat)
-    top1 = (int(pred) == int(label)) * 1.0
-    top5 = (int(label) in np.argsort(-feat)[:5]) * 1.0
-    return [pred, top1, top5, int(label)]
+    _, _, views, label = lst
+    score = np.mean(np.stack(list(views)), axis=0)
+    ranked = np.argsort(-score)
+    label = int(label)
+    return [ranked[0], float(ranked[0] == label), float(label in ranked[:5]), label]
+
+
+class ViewResults:
+    """The views of every video collected from the ranks' result files (``merge``): a view is identified by its temporal chunk and
+    spatial crop, and a view that a second rank wrote again (the distributed sampler pads the last batch) counts once."""
+
+    def __init__(self):
+        self.probs, self.seen, self.label = {}, {}, {}
+
+    def add_line(self, line: str) -> None:
+        import numpy as np
+        from scipy.special import softmax
+        line = line.strip()
+        name, _, rest = line.rpartition('[')                     # the id may contain spaces or brackets: split at the LAST '['
+        vector, _, tail = rest.rpartition(']')
+        label, chunk, split = tail.split(' ')[1:4]
+        views = self.probs.setdefault(name, [])
+        seen = self.seen.setdefault(name, set())
+        self.label.setdefault(name, 0)
+        key = chunk + split                                      # the reference's key: the two strings joined
+        if key in seen:
+            return
+        seen.add(key)
+        views.append(softmax(np.array([float(v) for v in vector.split(',')], dtype=np.float64)))
+        self.label[name] = label
+
+    def read(self, path: str) -> "ViewResults":
+        with open(path) as f:
+            next(f)                                              # first line: the writer's last-batch accuracies
+            for line in f:
+                self.add_line(line)
+        return self
+
+    def videos(self):
+        return [compute_video([i, name, views, self.label[name]]) for i, (name, views) in enumerate(self.probs.items())]
 
 
 def merge(eval_path, num_tasks):
-    """engine_for_finetuning.py:299-342: union of the ranks' '<rank>.txt' files, duplicate (chunk, split) views dropped, soft-max per
-    view, mean over views per video.  (np.float of the reference is gone from numpy >= 1.24: float64 here; no process pool.)"""
+    """engine_for_finetuning.py:299-342: union of the ranks' '<rank>.txt' files, soft-max per view, mean over the views of a video ->
+    top-1 / top-5 in percent.  (np.float of the reference is gone from numpy >= 1.24: float64 here; no process pool.)"""
     import os
     import numpy as np
-    from scipy.special import softmax
-    dict_feats, dict_label, dict_pos = {}, {}, {}
+    results = ViewResults()
     print("Reading individual output files")
-    for x in range(num_tasks):
-        file = os.path.join(eval_path, str(x) + '.txt')
-        for line in open(file, 'r').readlines()[1:]:
-            line = line.strip()
-            name = line.rsplit('[', maxsplit=1)[0]
-            tail = line.rsplit(']', maxsplit=1)[1].split(' ')
-            label, chunk_nb, split_nb = tail[1], tail[2], tail[3]
-            data = np.array([float(v) for v in line.rsplit('[', maxsplit=1)[1].rsplit(']', maxsplit=1)[0].split(',')], dtype=np.float64)
-            data = softmax(data)
-            if name not in dict_feats:
-                dict_feats[name], dict_label[name], dict_pos[name] = [], 0, []
-            if chunk_nb + split_nb in dict_pos[name]:
-                continue
-            dict_feats[name].append(data)
-            dict_pos[name].append(chunk_nb + split_nb)
-            dict_label[name] = label
+    for rank in range(num_tasks):
+        results.read(os.path.join(eval_path, f"{rank}.txt"))
     print("Computing final results")
-    ans = [compute_video([i, item, dict_feats[item], dict_label[item]]) for i, item in enumerate(dict_feats)]
-    top1, top5 = [x[1] for x in ans], [x[2] for x in ans]
-    return np.mean(top1) * 100, np.mean(top5) * 100
+    per_video = results.videos()
+    return np.mean([v[1] for v in per_video]) * 100, np.mean([v[2] for v in per_video]) * 100

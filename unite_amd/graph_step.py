@@ -7,8 +7,9 @@ and replayed with a single hipGraphLaunch.  What changes from step to step lives
 replays (``StepParams``): the learning rates / weight decays of the parameter groups (run_stage1.py:326-338 writes the schedule into
 ``optimizer.param_groups`` every step), Adam's bias corrections, and the seeds of the mask sampler and of stochastic depth.
 
-The engines use it through ``engine_stage1.train_one_epoch(..., args.hip_graph=True)`` / ``bench.py --graph``; data-parallel runs keep the
-eager step (the bucket all-reduces are issued through torch.distributed, whose capture on RCCL is untested here).
+Opt-in: ``GraphedStage1Step(model, teacher, optimizer, scaler, ...)`` is called directly (``bench.py --graph 1``, tests/test_model_gpu.py);
+``train_one_epoch`` runs eager launches (the replay measured slower than eager on this ROCm) and data-parallel
+runs keep the eager step (the bucket all-reduces are issued through torch.distributed, whose capture on RCCL is untested here).
 """
 from __future__ import annotations
 
