@@ -39,3 +39,89 @@ def test_run_stage1_synthetic(tmp_path):
     r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=500)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
     assert "Resume checkpoint" in r2.stdout and len(open(out / "log.txt").readlines()) == 1
+
+
+def _seeded_init(seed, build):
+    """the driver seeds torch with seed + rank and builds its model on the CPU before moving it: reproducible here"""
+    import numpy as np
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return {k: v.clone() for k, v in build().state_dict().items()}
+
+
+@pytest.mark.timeout(900)
+def test_run_stage2_synthetic(tmp_path):
+    """``python -m unite_amd.run_stage2 --config ... --synthetic`` (reference stage2.sh -> run_stage2.py:455-848): two epochs with update_freq 2,
+    layer-wise lr decay, --lp_ft_epochs 1 (blocks 0-8 + patch embedding frozen in epoch 0: run_stage2.py:741-746, trainable from epoch 1: :758),
+    validation every epoch with the best checkpoint kept, final_test + merge, the scalar logger fed per iteration."""
+    from types import SimpleNamespace
+    cfg = tmp_path / "stage2.yaml"
+    cfg.write_text(yaml.safe_dump(dict(
+        model="vit_base_patch16_224", nb_classes=5, num_frames=4, num_segments=1, tubelet_size=1, use_mean_pooling=True, init_scale=0.001,
+        drop_path=0.0, opt="adamw", opt_betas=[0.9, 0.999], lr=1e-3, min_lr=1e-6, warmup_epochs=0, epochs=2, batch_size=2, update_freq=2,
+        layer_decay=0.65, lr_schedule="cosine", eval_freq=1, save_ckpt_freq=1, frozen_layers="", lp_ft_epochs=1, test_best=False,
+        weight_decay=0.05, smoothing=0.0, input_size=224)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, "-m", "unite_amd.run_stage2", "--config", str(cfg), "--synthetic", "--synthetic_steps", "2", "--output_dir", str(out),
+           "--seed", "3"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert [l.get("epoch") for l in log[:2]] == [0, 1] and "Final top-1" in log[2]
+    assert log[0]["train_loss"] > 0 and "val_acc1" in log[0] and "train_grad_norm" in log[0]
+    assert (out / "checkpoint-best.pth").exists() and (out / "checkpoint-latest.pth").exists() and (out / "0.txt").exists()
+    scal = out / "scalars.jsonl"
+    if scal.exists():            # no tensorboard writer installed: launch.ScalarLog
+        rows = [json.loads(l) for l in open(scal)]
+        keys = {r_["key"] for r_ in rows}
+        assert {"loss/loss", "opt/lr", "opt/grad_norm", "perf/val_acc1"} <= keys
+        assert sum(r_["key"] == "loss/loss" for r_ in rows) == 2 * 4       # every iteration of both epochs (2 steps x update_freq 2)
+    # trainable-parameter schedule: epoch 0 leaves blocks 0-8 and the patch embedding exactly at their initial values
+    from unite_amd import run_stage2
+    a = SimpleNamespace(model="vit_base_patch16_224", nb_classes=5, num_frames=4, num_segments=1, tubelet_size=1, use_learnable_pos_emb=False,
+                        fc_drop_rate=0.0, drop=0.0, drop_path=0.0, attn_drop_rate=0.0, use_checkpoint=False, checkpoint_num=0,
+                        use_mean_pooling=True, init_scale=0.001, head_type="linear", head_hidden_dim=2048)
+    ck0 = torch.load(out / "checkpoint-0.pth", map_location="cpu", weights_only=True)["model"]
+    ck1 = torch.load(out / "checkpoint-1.pth", map_location="cpu", weights_only=True)["model"]
+    a.head_type = getattr(torch.load(out / "checkpoint-0.pth", map_location="cpu", weights_only=True)["args"], "head_type", "linear")
+    a.head_hidden_dim = getattr(torch.load(out / "checkpoint-0.pth", map_location="cpu", weights_only=True)["args"], "head_hidden_dim", 2048)
+    init = _seeded_init(3, lambda: run_stage2.get_model(a))
+    for k in ("patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.8.mlp.fc2.bias"):
+        assert torch.equal(ck0[k], init[k]), k                          # frozen in epoch 0
+        assert not torch.equal(ck1[k], ck0[k]), k                       # released at epoch lp_ft_epochs
+    for k in ("blocks.9.attn.qkv.weight", "blocks.11.mlp.fc1.weight", "head.weight"):
+        assert not torch.equal(ck0[k], init[k]), k
+
+
+@pytest.mark.timeout(900)
+def test_run_stage3_synthetic(tmp_path):
+    """``python -m unite_amd.run_stage3 --config ... --synthetic`` (reference stage3.sh -> run_stage3.py:992-1414): one epoch of two
+    source + target steps with the default clip_matchORconf selection (zero-shot probabilities from the frozen CLIP image tower against
+    seeded text features), validation, checkpoints and src_classifier_latest.pth; the source classifier and clip_decoder.* are not
+    optimised (Appendix A-8: the classifier is outside the optimizer; the decoders get no gradient in stage 3)."""
+    from types import SimpleNamespace
+    cfg = tmp_path / "stage3.yaml"
+    cfg.write_text(yaml.safe_dump(dict(
+        model="adaptation_umt_base_patch16_224", num_frames=8, tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+        clip_return_layers=[6], clip_teacher="clip_b16", clip_return_attn=True, mask_type="attention", mask_ratio=0.8, masking_type="clip_attention",
+        drop_path=0.0, opt="adamw", opt_betas=[0.9, 0.95], lr=1e-4, warmup_epochs=0, epochs=1, batch_size=2, log_freq=1, use_cls_token=False,
+        save_ckpt_freq=1, nb_classes=5, src_classifier_type="linear", class_loss_src_ratio=1.0, selection_strategy="clip_matchORconf",
+        clip_threshold=0.3, val_interval=1, return_aug_for_val=True, input_size=224)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, "-m", "unite_amd.run_stage3", "--config", str(cfg), "--synthetic", "--synthetic_steps", "2", "--output_dir", str(out),
+           "--seed", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert len(log) == 1 and log[0]["epoch"] == 0 and log[0]["train_loss"] > 0 and "train_select_ratio" in log[0] and "val_acc1" in log[0]
+    assert (out / "checkpoint-latest.pth").exists() and (out / "src_classifier_latest.pth").exists()
+    ck = torch.load(out / "checkpoint-latest.pth", map_location="cpu", weights_only=True)["model"]
+    from unite_amd import run_stage3
+    a = SimpleNamespace(model="adaptation_umt_base_patch16_224", drop_path=0.0, use_learnable_pos_emb=False, use_checkpoint=False, checkpoint_num=0,
+                        clip_decoder_embed_dim=768, clip_output_dim=512, clip_norm_type="l2", num_frames=8, tubelet_size=1, clip_return_layers=[6],
+                        clip_student_return_interval=1, use_cls_token=False)
+    init = _seeded_init(4, lambda: run_stage3.get_model(a))
+    assert torch.equal(ck["clip_decoder.0.head.weight"], init["clip_decoder.0.head.weight"])      # no gradient -> AdamW leaves it alone
+    assert not torch.equal(ck["encoder.blocks.0.attn.qkv.weight"], init["encoder.blocks.0.attn.qkv.weight"])
+    head = torch.load(out / "src_classifier_latest.pth", map_location="cpu", weights_only=True)
+    assert set(head) == {"weight", "bias"} and head["weight"].shape == (5, 768)

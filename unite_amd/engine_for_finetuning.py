@@ -46,6 +46,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         and criterion.reduction == "mean" and hasattr(net, "forward_loss")
     optimizer.zero_grad()
     pending = []
+    lr_now = [0.0, 0.0, None]          # max lr, min lr, weight decay of the iteration being logged
 
     def flush():
         if not pending:
@@ -60,6 +61,19 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             metric_logger.update(loss=lv, class_acc=av)
             if gv >= 0:
                 metric_logger.update(grad_norm=gv)
+            # engine_for_finetuning.py:134-167: the scalar logger and wandb see every iteration (here: when its scalars are read back)
+            if log_writer is not None:
+                log_writer.update(loss=lv, head="loss")
+                log_writer.update(class_acc=av, head="loss")
+                log_writer.update(loss_scale=loss_scaler.state_dict()["scale"], head="opt")
+                log_writer.update(lr=lr_now[0], head="opt")
+                log_writer.update(min_lr=lr_now[1], head="opt")
+                log_writer.update(weight_decay=lr_now[2], head="opt")
+                log_writer.update(grad_norm=gv if gv >= 0 else None, head="opt")
+                log_writer.set_step()
+            if wandb_run is not None:
+                wandb_run.log({"train/loss": lv, "train/class_acc": av, "train/lr": lr_now[0], "train/min_lr": lr_now[1],
+                               "train/weight_decay": lr_now[2], "train/grad_norm": gv if gv >= 0 else None})
 
     for data_iter_step, (samples, targets, _, _) in enumerate(metric_logger.log_every(data_loader, print_freq, num_epochs, epoch, ipe, header)):
         step = data_iter_step // update_freq
@@ -86,8 +100,6 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             optimizer.zero_grad()
         class_acc = (output.detach().max(-1)[-1] == targets).float().mean()
         pending.append((loss_log, class_acc, grad_norm))
-        if data_iter_step % print_freq == 0 or data_iter_step == ipe - 1:
-            flush()
         min_lr, max_lr = 10., 0.
         for group in optimizer.param_groups:
             min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
@@ -95,6 +107,9 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
         for group in optimizer.param_groups:
             if group["weight_decay"] > 0:
                 weight_decay_value = group["weight_decay"]
+        lr_now[:] = [max_lr, min_lr, weight_decay_value]
+        if data_iter_step % print_freq == 0 or data_iter_step == ipe - 1:
+            flush()
         metric_logger.update(lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value, loss_scale=loss_scaler.state_dict()["scale"])
     flush()
     metric_logger.synchronize_between_processes()

@@ -101,9 +101,12 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._chunk_group = self._build_chunk_table()
 
     def _effective_unused(self):
-        """name prefixes without a gradient this step: what the engine declared (set_unused) + what the model's runtime reports
-        (layers its last forward did not execute, e.g. blocks above the highest tap under clip_only)"""
-        return tuple(self._unused) + tuple(getattr(self._flat, "unused_prefixes", ()) or ())
+        """names (prefixes) without a gradient this step: what the engine declared (set_unused) + what the model's runtime reports (layers its
+        last forward did not execute, e.g. blocks above the highest tap under clip_only) + parameters whose requires_grad was switched
+        off AFTER the optimizer was built (run_stage2.py:711-746 freezes layers behind create_optimizer: autograd then leaves their
+        p.grad at None and torch.optim.AdamW skips them -- no moment update, no weight decay; --lp_ft_epochs switches them back on)"""
+        frozen = tuple(n for n, p in zip(self._flat.names, self._flat.params) if not p.requires_grad) if self._flat is not None else ()
+        return tuple(self._unused) + tuple(getattr(self._flat, "unused_prefixes", ()) or ()) + frozen
 
     def no_grad_chunks(self):
         """(chunk -> group table, id of the group without gradients) for the masked gradient norm; (None, -1) if every parameter has one"""

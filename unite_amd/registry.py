@@ -13,6 +13,11 @@ def register_model(fn: Callable) -> Callable:
 def create_model(model_name: str, pretrained: bool = False, **kwargs):
     if model_name not in _MODELS:
         raise RuntimeError(f"Unknown model ({model_name}); registered: {sorted(_MODELS)}")
+    # timm 0.4.12's create_model (the reference's pinned version) drops these three keyword arguments when they are None before it calls
+    # the entry point: that is how run_stage2.py:338 can pass drop_block_rate=None to a VisionTransformer that has no such parameter
+    for k in ("drop_block_rate", "drop_connect_rate", "drop_path_rate"):
+        if k in kwargs and kwargs[k] is None:
+            kwargs.pop(k)
     return _MODELS[model_name](pretrained=pretrained, **kwargs)
 
 
