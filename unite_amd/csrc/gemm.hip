@@ -925,14 +925,18 @@ struct Plan { int kind, splitk; double cost; };
 // does not read it.
 double g_plan_work = getenv("UNITE_GEMM_PLAN_WORK") ? atof(getenv("UNITE_GEMM_PLAN_WORK")) : 0.0;
 
-// split-K slabs are summed inside the launch by the last slice of each tile: one workgroup reads S slabs of its tile at the ~100 GB/s
-// a single workgroup gets from L2 / Infinity Cache (MI355X_MICROARCH.md, handoff-payload) -- 2.6 us per 256^2 slab, 0.65 us per 128^2 one
-inline double splitk_tail_us(int kind, int S) { return 1.5 + S * (kind == 2 ? 2.6 : 0.65); }
+// split-K slabs are summed inside the launch by the last slice of each tile: ONE workgroup reads S write-through slabs of its tile, a few
+// memory round trips of 16 loads per thread each -- measured (tools/wgrad_time.py sweeps, round 3) 2.4 us per 128^2 slab (64 KB) and
+// 6.5 us per 256^2 slab (256 KB), i.e. 27-40 GB/s for that one workgroup; the other slices' workgroups have left their CUs by then
+inline double splitk_tail_us(int kind, int S) { return 1.5 + S * (kind == 2 ? 6.5 : 2.4); }
 
-inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only, double work_weight) {
+// `tt`: both operands k-strided (weight gradients dY^T X): transposing fragment reads for A and B; fitted on the K = 10 240 sweeps of
+// tools/wgrad_time.py (128^2: 0.76 us per K-tile with one workgroup per CU, 1.15 with two; 256^2: 1.64)
+inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int only_kind, bool deep_only, double work_weight, bool tt = false) {
     const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
     const int slots[4] = {0, 512, 256, 512};
-    const double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
+    double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
+    if (tt) { cc[1] = 1.15; cc[2] = 1.64; }
     const int kt = (K + BK - 1) / BK;
     Plan best = {1, 1, 1e30};
     for (int kind = 1; kind <= 3; ++kind) {
@@ -943,12 +947,13 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
             if (S > 1 && (!can_split || kind == 3 || tiles[kind] > 4096 || (size_t)S * M * N * sizeof(float) > ws_bytes || kt / S < 4)) break;
             const int kts = (kt + S - 1) / S;
             const double rounds = (double)((tiles[kind] * S + slots[kind] - 1) / slots[kind]);
-            double cost = rounds * (kts * cc[kind] + ee[kind]);
+            const double c_eff = (tt && kind == 1 && tiles[kind] * S <= 256) ? 0.76 : cc[kind];      // a 128^2 workgroup alone on its CU
+            double cost = rounds * (kts * c_eff + ee[kind]);
             if (S > 1) cost += splitk_tail_us(kind, S);
             // work_weight > 0: the launch shares the GPU with an independent stream (teacher one batch ahead), so what it costs the step is
             // less its own latency than the CU time it takes: workgroups x time each, over the resident slots (+ the reducing workgroups' tails)
             if (work_weight > 0.0) {
-                double work = (double)tiles[kind] * S * (kts * cc[kind] + ee[kind]) / slots[kind];
+                double work = (double)tiles[kind] * S * (kts * cc[kind] + ee[kind]) / slots[kind];      // CU time at full occupancy
                 if (S > 1) work += (double)tiles[kind] * splitk_tail_us(kind, S) / slots[kind];
                 cost = (1.0 - work_weight) * cost + work_weight * work;
             }
@@ -1144,7 +1149,7 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     const double work_weight = (g.plan_flags & 2) ? (double)g.plan_sharing : g_plan_work;
     if (!(work_weight >= 0.0 && work_weight <= 1.0)) return UNITE_EINVAL;
     Plan plan = plan_gemm(g.M, g.N, g.K, can_split && !want_colsum, can_split ? (size_t)g.workspace_bytes - ws_head : 0,
-                          deep_only && only != 2 ? (only == 3 ? 0 : only) : only, deep_only, work_weight);
+                          deep_only && only != 2 ? (only == 3 ? 0 : only) : only, deep_only, work_weight, g.trans_a && g.trans_b);
     // tuning aid: UNITE_GEMM_FORCE_PLAN="kind,S" pins tile kernel (1: 128^2, 2: 256^2) and split factor for products that may split
     static const char* force_plan = getenv("UNITE_GEMM_FORCE_PLAN");
     if (force_plan && can_split && !want_colsum) {

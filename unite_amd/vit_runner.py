@@ -77,6 +77,9 @@ class ViTRunner:
         # student decoders on a side stream beside the encoder blocks (modeling_adaptation): shortens the student's serial chain by ~0.6 ms
         # at B = 32, but with the teacher one batch ahead the GPU is full either way: 20.71 vs 20.55 ms per step without it -> off
         self.side_decoders = os.environ.get("UNITE_DECODER_STREAM", "0") != "0"
+        # planner weight of the weight-gradient GEMMs (None: whatever the step runs under).  They sit on a side stream off the critical chain, so
+        # CU time, not latency, is what they cost an overlapped step: UNITE_WGRAD_SHARING pins the weight for A/B runs
+        self.wgrad_sharing = float(os.environ["UNITE_WGRAD_SHARING"]) if "UNITE_WGRAD_SHARING" in os.environ else None
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
         self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
@@ -246,7 +249,7 @@ class ViTRunner:
             ev = torch.cuda.Event()
             ev.record(main)
             sides[k].wait_event(ev)
-            with torch.cuda.stream(sides[k]):
+            with torch.cuda.stream(sides[k]), ops.plan(sharing=self.wgrad_sharing):
                 ev_fn(k)
                 if blk is not None:
                     e2 = torch.cuda.Event()
