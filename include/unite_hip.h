@@ -225,6 +225,16 @@ int unite_clip_similarity(const float* img, const float* text, float* out, int32
 int unite_clip_u8_to_f32(const uint8_t* frames, float* out, const uint8_t* flip, const float* mean3, const float* std3, int32_t B,
                          int32_t T, int32_t H, int32_t W, void* stream);
 
+/* Crop + resize of decoded uint8 frames on the device: frames (B,T,H,W,3) -> out (B,T,OH,OW,3), every frame of clip b cropped with
+ * the clip's box (x0, y0, w, h) and resized with the arithmetic of Pillow's ``img.resize((OW, OH), Image.BILINEAR)`` on 8-bit images,
+ * bit for bit (triangle filter with support max(w / OW, 1), 22-bit fixed-point weights, horizontal then vertical pass, each rounded
+ * to uint8): the reference's GroupMultiScaleCrop (src/datasets/transforms.py:136-152; build.py:37) without the PIL workers.
+ * boxes_host: HOST int32 [B][4] (the crop is drawn on the host: transforms.py:154-177); boxes up to 7.5 x the output side.
+ * workspace >= unite_crop_resize_workspace(B, T, H, OH, OW) bytes. */
+size_t unite_crop_resize_workspace(int32_t B, int32_t T, int32_t H, int32_t OH, int32_t OW);
+int unite_crop_resize_u8(const uint8_t* frames, const int32_t* boxes_host, uint8_t* out, int32_t B, int32_t T, int32_t H, int32_t W,
+                         int32_t OH, int32_t OW, void* workspace, void* stream);
+
 /* Bicubic resize of `planes` f32 images H x W -> OH x OW with the semantics of
  * torch.nn.functional.interpolate(mode='bicubic', align_corners=False) (A = -0.75, clamped taps):
  * the teacher-input resize of run_stage1.py:362-368 / run_stage3.py:438-445 (224 -> 196 for CLIP-L/14). */

@@ -182,3 +182,59 @@ def test_driver_side_utils_surface():
     assert utils.count_parameters(torch.nn.Linear(3, 4)) == 16
     with pytest.raises(NotImplementedError):
         utils.setup_clip(None, None)
+
+
+def test_frame_sampling_vs_reference_golden(golden_dir):
+    """data.get_seq_frames / sample_train_indices / frame_id_list against the reference's own methods (kinetics_sparse.py:283-312,
+    mae.py:253-287 compiled from the files' syntax trees by oracle/make_golden_sampling.py) on the same seeded ``random`` / ``numpy.random``
+    streams: training, validation, multi-view test and skip-strategy clips, videos shorter than the clip, jitter on and off."""
+    import json
+    import os
+    import random
+    import numpy as np
+    from unite_amd import data
+    z = json.load(open(os.path.join(golden_dir, "sampling.json")))
+    assert len(z["seq_frames"]) >= 12 and len(z["train_indices"]) >= 6
+    for c in z["seq_frames"]:
+        random.seed(c["seed"])
+        got = data.get_seq_frames(c["video_size"], c["num_frames"], clip_idx=c["clip_idx"], skip_frames=c["skip_frames"], mode=c["mode"],
+                                  test_num_segment=c["test_num_segment"])
+        assert [int(v) for v in got] == c["out"], c
+    for c in z["train_indices"]:
+        np.random.seed(c["seed"])
+        idx, skip = data.sample_train_indices(c["num_frames"], c["num_segments"], c["skip_length"], c["new_step"], c["temporal_jitter"])
+        assert [float(v) for v in idx] == c["indices"] and [int(v) for v in skip] == c["skip_offsets"], c
+        assert [int(v) for v in data.frame_id_list(c["num_frames"], idx, skip, c["skip_length"], c["new_step"])] == c["frame_ids"], c
+
+
+def test_crop_box_sampler_vs_reference_golden(golden_dir):
+    """data.MultiScaleCrop against GroupMultiScaleCrop._sample_crop_size (src/datasets/transforms.py:154-205, compiled from the file's syntax
+    tree by oracle/make_golden_sampling.py) on the same seeded ``random`` stream; the reference returns (w, h, x0, y0)."""
+    import json
+    import os
+    import random
+    from unite_amd import data
+    z = json.load(open(os.path.join(golden_dir, "sampling.json")))
+    assert len(z["crop_boxes"]) >= 6
+    for c in z["crop_boxes"]:
+        crop = data.MultiScaleCrop(c["input_size"], fix_crop=c["fix_crop"], more_fix_crop=c["more_fix_crop"])
+        random.seed(c["seed"])
+        for w, h, x0, y0 in c["draws"]:
+            assert crop(c["im_w"], c["im_h"]) == (x0, y0, w, h), c
+
+
+def test_pil_resize_oracle_vs_pillow():
+    """oracle/pil_resize.py (the checker of unite_crop_resize_u8) against Pillow itself: crop + Image.BILINEAR resize of random uint8
+    images, up- and down-scaling, bit for bit.  (Pillow is the reference's own resampler, transforms.py:136-152.)"""
+    import numpy as np
+    PIL_Image = pytest.importorskip("PIL.Image")
+    from oracle.pil_resize import crop_resize_bilinear
+    rng = np.random.RandomState(1)
+    for _ in range(12):
+        H, W = int(rng.randint(30, 300)), int(rng.randint(30, 300))
+        img = rng.randint(0, 256, (H, W, 3), dtype=np.uint8)
+        w, h = int(rng.randint(8, W + 1)), int(rng.randint(8, H + 1))
+        x0, y0 = int(rng.randint(0, W - w + 1)), int(rng.randint(0, H - h + 1))
+        OW, OH = int(rng.choice([224, 112, 37])), int(rng.choice([224, 112, 37]))
+        ref = np.asarray(PIL_Image.fromarray(img).crop((x0, y0, x0 + w, y0 + h)).resize((OW, OH), PIL_Image.BILINEAR))
+        assert np.array_equal(ref, crop_resize_bilinear(img, (x0, y0, w, h), (OH, OW)))

@@ -654,6 +654,64 @@ def test_clip_u8_to_f32_bit_exact_vs_reference_transform_order(ops):
     assert torch.equal(ClipToTensor()(ramp.to(DEV)).cpu(), O.clip_to_tensor(ramp, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD))
 
 
+def test_crop_resize_u8_bit_exact_vs_pillow_arithmetic(ops):
+    """unite_crop_resize_u8 == ``img.crop(box).resize((OW, OH), Image.BILINEAR)`` of every frame (the reference's GroupMultiScaleCrop,
+    transforms.py:136-152), bit for bit: against oracle/pil_resize.py (itself equal to Pillow: tests/test_host_logic.py) and, where Pillow
+    is installed, against Pillow directly.  Boxes: down-scaling by 1.5 and 3.2, up-scaling, equal size on one / both axes, ragged sizes."""
+    import numpy as np
+    from oracle.pil_resize import crop_resize_bilinear
+    g = torch.Generator().manual_seed(7)
+    B, T, H, W, S = 6, 3, 256, 340, 224
+    frames = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    boxes = [(42, 16, 256, 224), (0, 0, 340, 256), (129, 22, 168, 168), (58, 0, 224, 256), (10, 5, 224, 224), (3, 7, 100, 37)]
+    out = torch.empty(B, T, S, S, 3, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(ops.crop_resize_workspace(B, T, H, S, S), dtype=torch.uint8, device=DEV)
+    ops.crop_resize_u8(frames.to(DEV), boxes, out, ws)
+    got = out.cpu().numpy()
+    fr = frames.numpy()
+    for b in range(B):
+        for t in range(T):
+            assert np.array_equal(got[b, t], crop_resize_bilinear(fr[b, t], boxes[b], (S, S))), (b, t)
+    try:
+        from PIL import Image
+        for b in range(B):
+            x0, y0, w, h = boxes[b]
+            ref = np.asarray(Image.fromarray(fr[b, 0]).crop((x0, y0, x0 + w, y0 + h)).resize((S, S), Image.BILINEAR))
+            assert np.array_equal(got[b, 0], ref), b
+    except ImportError:
+        pass
+    # a box far larger than the output (7 x): 15 taps per position
+    big = torch.randint(0, 256, (1, 1, 800, 800, 3), generator=g, dtype=torch.uint8)
+    o2 = torch.empty(1, 1, 112, 112, 3, dtype=torch.uint8, device=DEV)
+    ws2 = torch.empty(ops.crop_resize_workspace(1, 1, 800, 112, 112), dtype=torch.uint8, device=DEV)
+    ops.crop_resize_u8(big.to(DEV), [(5, 9, 780, 784)], o2, ws2)
+    assert np.array_equal(o2.cpu().numpy()[0, 0], crop_resize_bilinear(big.numpy()[0, 0], (5, 9, 780, 784), (112, 112)))
+    from unite_amd._lib import UniteHipError
+    with pytest.raises(UniteHipError):
+        ops.crop_resize_u8(big.to(DEV), [(0, 0, 801, 10)], o2, ws2)          # box outside the frame
+
+
+def test_gpu_train_transform_vs_reference_transform_order(ops):
+    """data.GpuTrainTransform (crop box -> Pillow-bilinear resize -> flip -> HWC->CHW -> /255 -> normalise, all on the device) == the
+    oracle's restatement of build.py:34-54 on the same boxes and flips, bit for bit"""
+    import numpy as np
+    from oracle.pil_resize import crop_resize_bilinear
+    from unite_amd.data import GpuTrainTransform, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+    g = torch.Generator().manual_seed(11)
+    B, T, H, W, S = 3, 4, 120, 160, 64
+    frames = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    boxes = [(10, 4, 120, 105), (0, 0, 79, 79), (40, 20, 64, 64)]
+    flip = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    out = GpuTrainTransform(S)(frames.to(DEV), boxes=boxes, flip=flip.to(DEV))
+    resized = torch.from_numpy(np.stack([np.stack([crop_resize_bilinear(frames.numpy()[b, t], boxes[b], (S, S)) for t in range(T)]) for b in range(B)]))
+    ref = O.clip_to_tensor(resized, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, flip)
+    assert out.shape == (B, 3, T, S, S) and torch.equal(out.cpu(), ref)
+    # boxes drawn by the transform itself (reference sampler): shapes only
+    import random
+    out2 = GpuTrainTransform(S)(frames.to(DEV), rng=random.Random(3))
+    assert out2.shape == (B, 3, T, S, S) and torch.isfinite(out2).all()
+
+
 def test_clip_embed_ln_and_l2(ops):
     BT, HW, D = 3, 196, 768
     patches = bf(rnd(BT * HW, D, seed=1))

@@ -1,5 +1,6 @@
 // Gather / index / small reduction kernels of the stage-1 step (all HBM- or latency-bound, no MFMA).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -97,6 +98,96 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
         if (gc >= zero_lo && gc < zero_hi) a = 0.f;
         out[gc] = accumulate ? out[gc] + a : a;
     }
+}
+
+// ------------------------------------------------------------------------------------ crop + Pillow-bilinear resize of uint8 frames
+// The training transform of the reference crops every frame of a clip with ONE box and resizes the crop with Pillow's
+// img.resize((w, h), Image.BILINEAR) (src/datasets/transforms.py:136-152, build.py:37).  Pillow's 8-bit resample
+// (libImaging/Resample.c, pillow==10.0.1 in the reference's environment) is a separable triangle filter whose support grows with the
+// down-scaling factor, weights normalised in double and rounded to 22-bit fixed point, a horizontal pass rounded to uint8, then a
+// vertical pass rounded to uint8.  The same arithmetic here, bit for bit (oracle/pil_resize.py; tests compare with Pillow itself):
+//   coefficient kernel: per clip and axis, the tap range and fixed-point weights of every output position (double arithmetic);
+//   horizontal pass:    frames (B,T,H,W,3) -> tmp (B,T,H,OW,3) on the rows of the crop;   vertical pass: tmp -> out (B,T,OH,OW,3).
+constexpr int CR_KMAX = 16;            // taps per output position: 2 ceil(scale) + 1 <= 16, i.e. crops up to 7.5 x the output side
+constexpr int CR_MAXB = 64;            // clips per launch (the boxes travel as kernel arguments)
+constexpr int CR_PREC = 32 - 8 - 2;
+struct CropBoxes { int32_t x0[CR_MAXB], y0[CR_MAXB], w[CR_MAXB], h[CR_MAXB]; };
+
+__device__ __forceinline__ double cr_tri(double x) {
+    x = x < 0.0 ? -x : x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// grid (B, 2): axis 0 = x (in_size = box w, out OW), axis 1 = y.  bounds int32 [B][2][OMAX][2], kk int32 [B][2][OMAX][CR_KMAX]
+__global__ __launch_bounds__(256) void crop_resize_coeffs_kernel(const CropBoxes boxes, int OH, int OW, int OMAX, int32_t* __restrict__ bounds,
+                                                                 int32_t* __restrict__ kk) {
+    const int b = blockIdx.x, axis = blockIdx.y;
+    const int in_size = axis == 0 ? boxes.w[b] : boxes.h[b], out_size = axis == 0 ? OW : OH;
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale, ss = 1.0 / filterscale;
+    for (int xx = threadIdx.x; xx < out_size; xx += blockDim.x) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double w[CR_KMAX];
+        double ww = 0.0;
+#pragma unroll
+        for (int x = 0; x < CR_KMAX; ++x) {
+            w[x] = x < xmax ? cr_tri((x + xmin - center + 0.5) * ss) : 0.0;
+            if (x < xmax) ww += w[x];
+        }
+        int32_t* kp = kk + (((size_t)b * 2 + axis) * OMAX + xx) * CR_KMAX;
+#pragma unroll
+        for (int x = 0; x < CR_KMAX; ++x) {
+            double v = (x < xmax && ww != 0.0) ? w[x] / ww : w[x];
+            kp[x] = x < xmax ? (v < 0.0 ? (int32_t)(-0.5 + v * (double)(1 << CR_PREC)) : (int32_t)(0.5 + v * (double)(1 << CR_PREC))) : 0;
+        }
+        int32_t* bp = bounds + (((size_t)b * 2 + axis) * OMAX + xx) * 2;
+        bp[0] = xmin;
+        bp[1] = xmax;
+    }
+}
+
+__device__ __forceinline__ uint8_t cr_clip8(int32_t acc) {
+    const int32_t v = acc >> CR_PREC;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// one thread per output byte (ox, c) of a row: grid (ceil(OW*3 / 256), H rows of the crop at most, B*T)
+__global__ __launch_bounds__(256) void crop_resize_h_kernel(const uint8_t* __restrict__ frames, const CropBoxes boxes, uint8_t* __restrict__ tmp,
+                                                            const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int T, int H,
+                                                            int W, int OW, int OMAX) {
+    const int bt = blockIdx.z, b = bt / T, row = blockIdx.y;
+    if (row >= boxes.h[b]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= OW * 3) return;
+    const int ox = i / 3, c = i - ox * 3;
+    const int32_t* bp = bounds + (((size_t)b * 2 + 0) * OMAX + ox) * 2;
+    const int32_t* kp = kk + (((size_t)b * 2 + 0) * OMAX + ox) * CR_KMAX;
+    const int xmin = bp[0], n = bp[1];
+    const uint8_t* src = frames + (((size_t)bt * H + boxes.y0[b] + row) * W + boxes.x0[b] + xmin) * 3 + c;
+    int32_t acc = 1 << (CR_PREC - 1);
+    for (int x = 0; x < n; ++x) acc += (int32_t)src[x * 3] * kp[x];
+    tmp[((size_t)bt * H + row) * OW * 3 + i] = boxes.w[b] == OW ? src[(ox - xmin) * 3] : cr_clip8(acc);      // equal size: Pillow copies
+}
+
+__global__ __launch_bounds__(256) void crop_resize_v_kernel(const uint8_t* __restrict__ tmp, const CropBoxes boxes, uint8_t* __restrict__ out,
+                                                            const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int T, int H,
+                                                            int OH, int OW, int OMAX) {
+    const int bt = blockIdx.z, b = bt / T, oy = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= OW * 3) return;
+    const int32_t* bp = bounds + (((size_t)b * 2 + 1) * OMAX + oy) * 2;
+    const int32_t* kp = kk + (((size_t)b * 2 + 1) * OMAX + oy) * CR_KMAX;
+    const int ymin = bp[0], n = bp[1];
+    const uint8_t* src = tmp + ((size_t)bt * H + ymin) * OW * 3 + i;
+    int32_t acc = 1 << (CR_PREC - 1);
+    for (int y = 0; y < n; ++y) acc += (int32_t)src[(size_t)y * OW * 3] * kp[y];
+    out[((size_t)bt * OH + oy) * OW * 3 + i] = boxes.h[b] == OH ? src[(size_t)(oy - ymin) * OW * 3] : cr_clip8(acc);
 }
 
 // ------------------------------------------------------------------------------------ mask sampling
@@ -622,6 +713,52 @@ extern "C" int unite_colsum_bf16(const void* x, int32_t ldx, int32_t M, int32_t 
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, nparts), dim3(256), 0, s, (const uint16_t*)x, ldx, M, N, (char*)workspace, out,
                        accumulate, zero_lo, zero_hi);
     UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+static inline size_t cr_align(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t unite_crop_resize_workspace(int32_t B, int32_t T, int32_t H, int32_t OH, int32_t OW) {
+    const size_t omax = (size_t)(OH > OW ? OH : OW), nb = (size_t)(B < CR_MAXB ? B : CR_MAXB);
+    return cr_align(nb * 2 * omax * 2 * 4) + cr_align(nb * 2 * omax * CR_KMAX * 4) + cr_align(nb * (size_t)T * H * OW * 3);
+}
+
+extern "C" int unite_crop_resize_u8(const uint8_t* frames, const int32_t* boxes_host, uint8_t* out, int32_t B, int32_t T, int32_t H, int32_t W,
+                                    int32_t OH, int32_t OW, void* workspace, void* stream) {
+    if (!frames || !boxes_host || !out || !workspace || B <= 0 || T <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return UNITE_EINVAL;
+    if ((size_t)B * T > 65535 * 64 || H > 65535 || OH > 65535) return UNITE_ENOSUP;
+    const int omax = OH > OW ? OH : OW;
+    hipStream_t s = (hipStream_t)stream;
+    for (int b0 = 0; b0 < B; b0 += CR_MAXB) {
+        const int nb = B - b0 < CR_MAXB ? B - b0 : CR_MAXB;
+        CropBoxes bx;
+        memset(&bx, 0, sizeof(bx));
+        int hmax = 0;
+        for (int i = 0; i < nb; ++i) {
+            const int32_t* q = boxes_host + (size_t)(b0 + i) * 4;
+            if (q[0] < 0 || q[1] < 0 || q[2] <= 0 || q[3] <= 0 || q[0] + q[2] > W || q[1] + q[3] > H) return UNITE_EINVAL;
+            // taps per output position: 2 ceil(max(in / out, 1)) + 1 must fit CR_KMAX
+            if (2 * ((q[2] + OW - 1) / OW > 1 ? (q[2] + OW - 1) / OW : 1) + 1 > CR_KMAX || 2 * ((q[3] + OH - 1) / OH > 1 ? (q[3] + OH - 1) / OH : 1) + 1 > CR_KMAX)
+                return UNITE_ENOSUP;
+            bx.x0[i] = q[0]; bx.y0[i] = q[1]; bx.w[i] = q[2]; bx.h[i] = q[3];
+            hmax = q[3] > hmax ? q[3] : hmax;
+        }
+        const size_t nbw = (size_t)(B < CR_MAXB ? B : CR_MAXB);       // the layout unite_crop_resize_workspace sized
+        char* ws = (char*)workspace;
+        int32_t* bounds = (int32_t*)ws;
+        int32_t* kk = (int32_t*)(ws + cr_align(nbw * 2 * omax * 2 * 4));
+        uint8_t* tmp = (uint8_t*)((char*)kk + cr_align(nbw * 2 * omax * CR_KMAX * 4));
+        const uint8_t* fr = frames + (size_t)b0 * T * H * W * 3;
+        uint8_t* op = out + (size_t)b0 * T * OH * OW * 3;
+        hipLaunchKernelGGL(crop_resize_coeffs_kernel, dim3(nb, 2), dim3(256), 0, s, bx, OH, OW, omax, bounds, kk);
+        UNITE_LAUNCH_CHECK();
+        const unsigned gx = (unsigned)((OW * 3 + 255) / 256);
+        hipLaunchKernelGGL(crop_resize_h_kernel, dim3(gx, hmax, nb * T), dim3(256), 0, s, fr, bx, tmp, (const int32_t*)bounds, (const int32_t*)kk, T, H, W,
+                           OW, omax);
+        UNITE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(crop_resize_v_kernel, dim3(gx, OH, nb * T), dim3(256), 0, s, (const uint8_t*)tmp, bx, op, (const int32_t*)bounds,
+                           (const int32_t*)kk, T, H, OH, OW, omax);
+        UNITE_LAUNCH_CHECK();
+    }
     return UNITE_OK;
 }
 

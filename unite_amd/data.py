@@ -41,6 +41,65 @@ class ClipToTensor:
         return ops.clip_u8_to_f32(frames.contiguous(), self._out, self.mean, self.std, flip)
 
 
+class MultiScaleCrop:
+    """Which box of a clip the training transform keeps (reference GroupMultiScaleCrop._sample_crop_size, src/datasets/transforms.py:154-205;
+    tests/golden/sampling.json holds that method's own draws): side lengths are the short side of the frame times one of ``scales``
+    (snapped to the network's input size when within 3 pixels), width and height at most ``max_distort`` scale steps apart, the position
+    one of 5 (13 with ``more_fix_crop``) anchor points of a 4 x 4 grid of the slack, or uniform without ``fix_crop``.  Returns
+    (x0, y0, w, h) -- the order unite_crop_resize_u8 takes; ``rng`` is a ``random.Random``-like object (default: the ``random`` module)."""
+
+    def __init__(self, input_size, scales=(1, .875, .75, .66), max_distort=1, fix_crop=True, more_fix_crop=True):
+        self.input_size = (input_size, input_size) if isinstance(input_size, int) else tuple(input_size)
+        self.scales, self.max_distort, self.fix_crop, self.more_fix_crop = tuple(scales), max_distort, fix_crop, more_fix_crop
+
+    def anchors(self, slack_w: int, slack_h: int):
+        qw, qh = slack_w // 4, slack_h // 4
+        grid = [(0, 0), (4, 0), (0, 4), (4, 4), (2, 2)]                               # corners, centre
+        if self.more_fix_crop:
+            grid += [(0, 2), (4, 2), (2, 4), (2, 0), (1, 1), (3, 1), (1, 3), (3, 3)]  # edge centres, quarter points
+        return [(i * qw, j * qh) for i, j in grid]
+
+    def __call__(self, im_w: int, im_h: int, rng=None):
+        import random as _random
+        rng = _random if rng is None else rng
+        short = min(im_w, im_h)
+        sides = [int(short * s) for s in self.scales]
+        ws = [self.input_size[0] if abs(v - self.input_size[0]) < 3 else v for v in sides]
+        hs = [self.input_size[1] if abs(v - self.input_size[1]) < 3 else v for v in sides]
+        w, h = rng.choice([(ws[j], hs[i]) for i in range(len(hs)) for j in range(len(ws)) if abs(i - j) <= self.max_distort])
+        if self.fix_crop:
+            x0, y0 = rng.choice(self.anchors(im_w - w, im_h - h))
+        else:
+            x0 = rng.randint(0, im_w - w)
+            y0 = rng.randint(0, im_h - h)
+        return x0, y0, w, h
+
+
+class GpuTrainTransform:
+    """The training transform of build.py:34-54 (GroupMultiScaleCrop -> GroupRandomHorizontalFlip -> Stack -> ToTorchFormatTensor ->
+    GroupNormalize) on the device: decoded uint8 frames (B,T,H,W,3) in, the engines' f32 (B,3,T,S,S) clip out.  One crop box per clip
+    (drawn on the host like the reference does), unite_crop_resize_u8 (Pillow-bilinear arithmetic, bit for bit), then ClipToTensor."""
+
+    def __init__(self, input_size: int, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, flip_prob: float = 0.0, seed: int = 0):
+        self.size, self.crop = int(input_size), MultiScaleCrop(input_size)
+        self.to_tensor = ClipToTensor(mean, std, flip_prob, seed)
+        self._u8, self._ws = None, None
+
+    def __call__(self, frames: torch.Tensor, boxes=None, flip: Optional[torch.Tensor] = None, rng=None) -> torch.Tensor:
+        if frames.device.type != "cuda":
+            raise RuntimeError("GpuTrainTransform runs on the MI355X only (no CPU path): move the uint8 frames to 'cuda' first")
+        B, T, H, W, _ = frames.shape
+        if boxes is None:
+            boxes = [self.crop(W, H, rng) for _ in range(B)]
+        if self._u8 is None or tuple(self._u8.shape) != (B, T, self.size, self.size, 3):
+            self._u8 = torch.empty(B, T, self.size, self.size, 3, dtype=torch.uint8, device=frames.device)
+        need = ops.crop_resize_workspace(B, T, H, self.size, self.size)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=frames.device)
+        ops.crop_resize_u8(frames.contiguous(), boxes, self._u8, self._ws)
+        return self.to_tensor(self._u8, flip)
+
+
 class DistributedSampler(torch.utils.data.Sampler):
     """Which samples a rank sees in an epoch: the reference's sampler (src/datasets/distributed.py:81-163), i.e. torch's
     ``DistributedSampler`` plus ``repetitions`` -- the epoch is `repetitions` independent permutations of the dataset laid end to
@@ -102,13 +161,37 @@ class DistributedSampler(torch.utils.data.Sampler):
         self.epoch = epoch
 
 
+def get_seq_frames(video_size: int, num_frames: int, clip_idx: int = -1, skip_frames: int = 0, mode: str = "train",
+                   test_num_segment: int = 1, rng=None):
+    """Frame numbers of one clip of a video, as the reference's sparse dataset draws them (src/datasets/kinetics_sparse.py:283-312
+    ``VideoClsDataset_sparse._get_seq_frames``; tests/golden/sampling.json holds that method's own output on seeded streams).
+    Sparse strategy (skip_frames <= 0): the video is cut into ``num_frames`` equal segments; training (clip_idx == -1) takes one uniformly
+    drawn frame of each segment (both ends included, so neighbours can share a frame), evaluation takes the frame a fixed fraction
+    (clip_idx + 1) / (segments_of_the_view + 1) into each segment.  Skip strategy: ``num_frames`` frames ``skip_frames`` apart from a random
+    start.  Indices never pass the last frame.  ``rng``: a ``random.Random``-like object (default: the ``random`` module, as the
+    reference uses)."""
+    import random as _random
+    import numpy as np
+    rng = _random if rng is None else rng
+    last = int(video_size) - 1
+    if skip_frames > 0:
+        first = rng.randint(0, max(0, last - num_frames * skip_frames))
+        return [min(first + k * skip_frames, last) for k in range(num_frames)]
+    seg = max(0., float(video_size - 1) / num_frames)
+    edges = [int(np.round(seg * i)) for i in range(num_frames + 1)]
+    if clip_idx == -1:
+        return [min(rng.randint(edges[i], edges[i + 1]), last) for i in range(num_frames)]
+    views = test_num_segment if mode == 'test' else 1
+    into = int(seg / (views + 1) * (clip_idx + 1))
+    return [min(edges[i] + into, last) for i in range(num_frames)]
+
+
 def sample_train_indices(num_frames: int, num_segments: int, skip_length: int = 1, new_step: int = 1, temporal_jitter: bool = False,
                          rng=None):
     """Sparse (TSN-style) frame sampling of a training clip: one random frame per equal-length segment of the video, 1-based
     segment offsets + per-step jitter offsets (reference src/datasets/mae.py:253-273, drawing from numpy's global generator in
     the same order: segment offsets first, then the jitter).  `rng`: a numpy RandomState / module with ``randint`` (default
-    ``numpy.random``).  PARITY UNPINNED by the reference (its module imports decord and cv2, absent here): pinned by the properties
-    in tests/test_host_logic.py only."""
+    ``numpy.random``).  Pinned on the reference method's own output (tests/golden/sampling.json, oracle/make_golden_sampling.py)."""
     import numpy as np
     rng = np.random if rng is None else rng
     seg_len = (num_frames - skip_length + 1) // num_segments
@@ -125,7 +208,7 @@ def sample_train_indices(num_frames: int, num_segments: int, skip_length: int = 
 
 def frame_id_list(duration: int, indices, skip_offsets, skip_length: int = 1, new_step: int = 1):
     """0-based frame numbers to decode for the sampled segment offsets (reference src/datasets/mae.py:275-287): `skip_length /
-    new_step` frames per segment, `new_step` apart, clamped so that no frame lies beyond the video.  PARITY UNPINNED, as above."""
+    new_step` frames per segment, `new_step` apart, clamped so that no frame lies beyond the video.  Pinned as above."""
     out = []
     for seg in indices:
         offset = int(seg)

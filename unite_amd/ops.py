@@ -308,6 +308,24 @@ def clip_u8_to_f32(frames, out, mean, std, flip=None):
     return out
 
 
+def crop_resize_workspace(B: int, T: int, H: int, OH: int, OW: int) -> int:
+    return int(_lib.load().unite_crop_resize_workspace(B, T, H, OH, OW))
+
+
+def crop_resize_u8(frames, boxes, out, workspace):
+    """frames uint8 (B,T,H,W,3) on the device, boxes: B host tuples (x0, y0, w, h), out uint8 (B,T,OH,OW,3): per-clip crop +
+    Pillow-bilinear resize (unite_crop_resize_u8)"""
+    lib = _lib.load()
+    _req(frames, torch.uint8, "frames"); _req(out, torch.uint8, "out")
+    B, T, H, W, Cc = frames.shape
+    OH, OW = out.shape[2], out.shape[3]
+    assert Cc == 3 and frames.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, T, OH, OW, 3) and len(boxes) == B
+    flat = [int(v) for box in boxes for v in box]
+    arr = (C.c_int32 * (4 * B))(*flat)
+    _lib.check(lib.unite_crop_resize_u8(_ptr(frames), arr, _ptr(out), B, T, H, W, OH, OW, _ptr(workspace), _stream()), "unite_crop_resize_u8")
+    return out
+
+
 def resize_bicubic(video, out):
     """(B,C,T,H,W) f32 -> out (B,C,T,OH,OW): per-plane bicubic resize, align_corners=False."""
     lib = _lib.load()
