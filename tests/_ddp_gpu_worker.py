@@ -125,6 +125,24 @@ def main():
         lf2.backward()
         torch.cuda.synchronize()
         res["s2.full_grad"] = vf.runtime().fp.grad.clone().cpu()
+    # ---------------- AdamW per gradient bucket (UNITE_BUCKET_ADAMW / scaler.bucket_adamw) vs one launch after the whole backward
+    def train(bucket):
+        s3 = student()
+        m3 = DistributedDataParallel(s3)
+        a3 = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=2e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95])
+        opt3 = create_optimizer(a3, s3, skip_list=s3.no_weight_decay())
+        sc = NativeScalerWithGradNormCount()
+        sc.bucket_adamw = bucket
+        gns = []
+        res["s1.init_params"] = s3.runtime().fp.param.clone().cpu()
+        for it in range(3):
+            l3 = stage1_step(m3, t, mine, per, 0.5, 'attention', None, 'mixed', StepState(), clip_input_resolution=32, importance=imp_mine)
+            opt3.zero_grad()
+            gns.append(sc(l3, opt3, clip_grad=None, parameters=None, reducer=m3.reducer).item())
+        torch.cuda.synchronize()
+        return s3.runtime().fp.param.clone().cpu(), gns
+    res["s1.opt_params"], res["s1.opt_gn"] = train(False)
+    res["s1.bucket_params"], res["s1.bucket_gn"] = train(True)
     torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -41,6 +41,18 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, local)
         ref = torch.stack(gathered).mean(0)
         assert torch.allclose(grad, ref, atol=1e-6), (rank, step)
+    # after_bucket (the hook FusedAdamW.step_range hangs on): once per bucket, with the bucket's range, when its slice already holds the mean
+    grad.copy_(torch.randn(n, generator=g))
+    gathered = [torch.empty(n) for _ in range(world)]
+    dist.all_gather(gathered, grad.clone())
+    ref = torch.stack(gathered).mean(0)
+    seen = []
+    red.after_bucket = lambda lo, hi: seen.append((lo, hi, bool(torch.allclose(grad[lo:hi], ref[lo:hi], atol=1e-6))))
+    for t, _, _ in tags:
+        red.layer_done(t)
+    red.finish()
+    red.after_bucket = None
+    assert seen == [(2 * 2048, 5 * 2048, True), (0, 2 * 2048, True)], seen
     # a layer that never reports (unused parameters) is still reduced by finish()
     grad.copy_(torch.full((n,), float(rank)))
     red.layer_done(4)

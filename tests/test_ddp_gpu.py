@@ -53,6 +53,10 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     assert torch.equal(r0["s1.ahead_grad"], r1["s1.ahead_grad"])
     assert rel_l2(r0["s1.ahead_grad"], r0["s1.grad"]) <= 1e-5
     assert abs(r0["s1.ahead_loss"] - r0["s1.loss"]) <= 2e-6 * abs(r0["s1.loss"])
+    # AdamW of each bucket right behind its all-reduce (opt-in) == the single launch after the backward, bit for bit, over three steps
+    assert torch.equal(r0["s1.opt_params"], r1["s1.opt_params"]) and torch.equal(r0["s1.bucket_params"], r1["s1.bucket_params"])
+    assert torch.equal(r0["s1.bucket_params"], r0["s1.opt_params"])
+    assert r0["s1.bucket_gn"] == r0["s1.opt_gn"] and not torch.equal(r0["s1.opt_params"], r0["s1.init_params"])
     # stage 2: one collective per bucket for the whole accumulation step, gradient = full-batch mean-CE gradient
     assert torch.equal(r0["s2.grad"], r1["s2.grad"])
     assert rel_l2(r0["s2.grad"], r0["s2.full_grad"]) <= 2e-3

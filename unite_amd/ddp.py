@@ -94,6 +94,9 @@ class GradReducer:
         # all-reduces every micro-batch; reducing the accumulated sum once is the same mean at 1 / update_freq of the traffic)
         self.enabled = True
         self.launched = 0                # collectives issued since construction (tests / diagnostics)
+        # optional ``after_bucket(lo, hi)``: called once per bucket when its reduced (averaged) gradients are in place -- on the reducer's
+        # stream right behind the collective (RCCL), or at finish() (gloo).  FusedAdamW.step_range hangs here (UNITE_BUCKET_ADAMW=1).
+        self.after_bucket = None
         self.reset()
 
     def reset(self):
@@ -130,6 +133,8 @@ class GradReducer:
 
     def _launch(self, i):
         if self.world == 1:
+            if self.after_bucket is not None:      # one rank: nothing to reduce, the bucket is final as it stands
+                self.after_bucket(self.buckets[i]["lo"], self.buckets[i]["hi"])
             return
         b = self.buckets[i]
         view = self.grad[b["lo"]:b["hi"]]
@@ -144,12 +149,15 @@ class GradReducer:
             else:
                 with torch.cuda.stream(self.stream):
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+            if self.after_bucket is not None:
+                with torch.cuda.stream(self.stream):
+                    self.after_bucket(b["lo"], b["hi"])
         else:
             if self.use_stream:          # gloo on device tensors stages through the host from the CURRENT stream
                 for ev in self._events[i]:
                     torch.cuda.current_stream().wait_event(ev)
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # gloo has no AVG
-            self._works.append((w, view))
+            self._works.append((w, view, (b["lo"], b["hi"])))
         self._events[i] = []
 
     def finish(self):
@@ -168,9 +176,11 @@ class GradReducer:
         if self.use_stream and self.native_avg:
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
-            for w, view in self._works:
+            for w, view, rng in self._works:
                 w.wait()
                 view.div_(self.world)
+                if self.after_bucket is not None:
+                    self.after_bucket(*rng)
         self.reset()
 
 

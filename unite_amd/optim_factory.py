@@ -181,6 +181,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
         if not self._ready:
             self._prepare()
+        if getattr(self, "_open", None) is not None:      # begin_step() ... step_range() ...: update what is left, close the step
+            self._finish_open_step(grad_scale)
+            return
         fp = self._flat
         b1, b2 = self.param_groups[0]["betas"]
         if self._step_params is not None:
@@ -192,6 +195,45 @@ class FusedAdamW(torch.optim.Optimizer):
         lrs, wds = self._hparams()
         ops.adamw_flat(fp.param, fp.grad, self.exp_avg, self.exp_avg_sq, fp.shadow, self._chunk_group, lrs, wds,
                        float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step, grad_scale=grad_scale, found_inf=found_inf)
+
+    # ---- AdamW per gradient bucket (opt-in: UNITE_BUCKET_ADAMW=1 / NativeScalerWithGradNormCount.bucket_adamw)
+    # No shipped config clips gradients, so a layer's update needs nothing but its own (reduced) gradient: ``begin_step()`` fixes this
+    # step's count and hyper-parameters, ``step_range(lo, hi)`` updates one 1024-aligned range of the flat buffer (the reducer calls it
+    # behind each bucket's all-reduce, on the reducer's stream: the optimizer then overlaps the remaining backward and communication),
+    # and the closing ``step()`` covers whatever no bucket touched.  Element for element the arithmetic is that of the single launch.
+    @torch.no_grad()
+    def begin_step(self):
+        if self._step_params is not None:
+            raise RuntimeError("per-bucket AdamW and the captured (device-parameter) step are mutually exclusive")
+        if not self._ready:
+            self._prepare()
+        self._refresh_unused()
+        self._step += 1
+        self._open = dict(hp=self._hparams(), done=[])
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int, grad_scale: Optional[torch.Tensor] = None):
+        from .flat_params import CHUNK
+        if getattr(self, "_open", None) is None:
+            raise RuntimeError("step_range() outside begin_step() ... step()")
+        if lo % CHUNK or hi % CHUNK or not 0 <= lo < hi <= self._flat.total:
+            raise ValueError("ranges are whole 1024-element chunks of the flat buffer")
+        fp = self._flat
+        b1, b2 = self.param_groups[0]["betas"]
+        lrs, wds = self._open["hp"]
+        ops.adamw_flat(fp.param[lo:hi], fp.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], fp.shadow[lo:hi],
+                       self._chunk_group[lo // CHUNK:hi // CHUNK], lrs, wds, float(b1), float(b2), float(self.param_groups[0]["eps"]),
+                       self._step, grad_scale=grad_scale)
+        self._open["done"].append((lo, hi))
+
+    def _finish_open_step(self, grad_scale=None):
+        done = sorted(self._open["done"])
+        pos = 0
+        for lo, hi in done + [(self._flat.total, self._flat.total)]:
+            if lo > pos:
+                self.step_range(pos, lo, grad_scale)
+            pos = max(pos, hi)
+        self._open = None
 
     def zero_grad(self, set_to_none: bool = True):
         """The next backward overwrites the flat gradient buffer instead of adding to it: no 352 MB memset."""

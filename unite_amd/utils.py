@@ -32,6 +32,9 @@ class NativeScalerWithGradNormCount:
         self._norm = None
         self._coef = None
         self._ws = None
+        # AdamW of each gradient bucket right behind its all-reduce instead of one launch after the whole backward (opt-in; only without
+        # gradient clipping: the clip coefficient needs every gradient first).  Same parameters bit for bit (tests/test_ddp_gpu.py).
+        self.bucket_adamw = os.environ.get("UNITE_BUCKET_ADAMW", "0") == "1"
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True, reducer=None):
         if reducer is not None and not update_grad:
@@ -41,11 +44,21 @@ class NativeScalerWithGradNormCount:
                 loss.backward(create_graph=create_graph)
             reducer.reset()
             return None
-        loss.backward(create_graph=create_graph)
+        per_bucket = (self.bucket_adamw and reducer is not None and update_grad and not (clip_grad is not None and clip_grad > 0)
+                      and hasattr(optimizer, "begin_step") and getattr(optimizer, "_step_params", None) is None)
+        if per_bucket:
+            optimizer.begin_step()
+            reducer.after_bucket = optimizer.step_range
+        try:
+            loss.backward(create_graph=create_graph)
+        finally:
+            if per_bucket and not update_grad:
+                reducer.after_bucket = None
         if not update_grad:
             return None
         if reducer is not None:
             reducer.finish()                          # join the gradient all-reduce (side stream) before reading grads
+            reducer.after_bucket = None
         flat = getattr(optimizer, "_flat", None)
         if flat is None:
             raise RuntimeError("optimizer is not a unite_amd FusedAdamW bound to a flat parameter buffer")
