@@ -618,7 +618,15 @@ int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_by
         }
         lds_ok = true;
     }
-    const int grid = p.ntiles < 256 ? p.ntiles : 256;
+    // UNITE_PP_WALK=k (experiment): workgroups of at most k tiles instead of one workgroup per CU for the whole product -- the finished tile
+    // still drains under the next one inside a workgroup, but CUs change hands every k tiles (a launch beside another stream's kernels)
+    static const int walk = getenv("UNITE_PP_WALK") ? atoi(getenv("UNITE_PP_WALK")) : 0;
+    int grid = p.ntiles < 256 ? p.ntiles : 256;
+    if (walk > 0) {
+        int g2 = ((p.ntiles + walk - 1) / walk + 7) & ~7;
+        if (g2 > p.ntiles) g2 = p.ntiles;
+        if (g2 > grid) grid = g2;
+    }
     if (g.out_f32) hipLaunchKernelGGL((gemm_pp_kernel<false, true>), dim3(grid), dim3(512), PP_LDS, s, p);
     else if (g.trans_b) hipLaunchKernelGGL((gemm_pp_kernel<true, false>), dim3(grid), dim3(512), PP_LDS, s, p);
     else hipLaunchKernelGGL((gemm_pp_kernel<false, false>), dim3(grid), dim3(512), PP_LDS, s, p);
