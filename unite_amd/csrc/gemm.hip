@@ -48,6 +48,8 @@ struct Params {
     int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
     float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
+    int32_t group_rows;           // deep kernels: tiles run column-major inside groups of this many tile rows (<= 1: plain row-major order), so
+                                  // that the workgroups resident on an XCD share few A panels AND few B panels of its 4-MiB L2
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -413,7 +415,14 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const int gM = g.M, gN = g.N, gK = g.K, lda = g.lda, ldb = g.ldb;
     const int nbn = (gN + TILE - 1) / TILE, nbm = (gM + TILE - 1) / TILE, nb = nbm * nbn;
     const int tile = (lin - lin0) % nb, slice = (lin - lin0) / nb;
-    const int m0 = (tile / nbn) * TILE, n0 = (tile % nbn) * TILE;
+    int tm = tile / nbn, tn = tile % nbn;
+    if (p.group_rows > 1) {          // column-major inside a group of tile rows (the last group may be shorter)
+        const int per = p.group_rows * nbn, gq = tile / per, within = tile - gq * per;
+        const int rows = min(p.group_rows, nbm - gq * p.group_rows);
+        tn = within / rows;
+        tm = gq * p.group_rows + (within - tn * rows);
+    }
+    const int m0 = tm * TILE, n0 = tn * TILE;
     const int k_begin = slice * p.k_chunk, k_end = min(gK, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
@@ -1182,6 +1191,10 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         p.slab = (float*)((char*)g.workspace + ws_head);
     }
     const int nb = tiles * p.splitk;
+    {
+        static const int gr_env = getenv("UNITE_GEMM_GROUP_ROWS") ? atoi(getenv("UNITE_GEMM_GROUP_ROWS")) : -1;
+        p.group_rows = gr_env >= 0 ? gr_env : 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
     if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
