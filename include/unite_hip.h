@@ -261,7 +261,7 @@ int unite_l2_normalize_rows(float* x, int32_t M, int32_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Attention-guided mask sampling (run_stage1.py:379-387): per frame row of `weights`
- * (f32 [BT, N], N <= 256) draw a weighted permutation without replacement and keep its first
+ * (f32 [BT, N], N <= 1024) draw a weighted permutation without replacement and keep its first
  * n_vis entries visible.  Implemented as an exponential race (key = -log(u)/w, keep the n_vis
  * smallest): the same distribution as torch.multinomial(w, N)[:, :n_vis] as a SET.
  *   mask    : uint8 [BT*N], 1 = masked          vis_tokens : int32 [BT*n_vis] global token ids

@@ -729,9 +729,10 @@ def test_clip_embed_ln_and_l2(ops):
 
 
 # ------------------------------------------------------------------------------------ masks
-def test_mask_from_importance_matches_reference_rule(ops):
+@pytest.mark.parametrize("N,n_vis", [(196, 40), (576, 116), (1024, 7)])           # 224 @ 16; CLIP-L/14 @ 336 (24 x 24 patches); the kernel's limit
+def test_mask_from_importance_matches_reference_rule(ops, N, n_vis):
     from oracle.filler import make_importance
-    B, T, N, n_vis = 3, 8, 196, 40
+    B, T = 3, 8
     imp = make_importance(B * T, N, seed=5)
     ref = O.mask_from_importance(imp, n_vis, B)
     mask = torch.empty(B * T * N, dtype=torch.uint8, device=DEV)
@@ -746,8 +747,8 @@ def test_mask_from_importance_matches_reference_rule(ops):
     assert torch.equal(vis2, vis)
 
 
-def test_mask_sample_properties_and_distribution(ops):
-    BT, N, n_vis = 4096, 196, 40
+@pytest.mark.parametrize("BT,N,n_vis", [(4096, 196, 40), (8192, 576, 116)])
+def test_mask_sample_properties_and_distribution(ops, BT, N, n_vis):
     w = torch.rand(N, generator=torch.Generator().manual_seed(1)) ** 3 + 1e-3
     w = (w / w.sum()).repeat(BT, 1)
     mask = torch.empty(BT * N, dtype=torch.uint8, device=DEV)

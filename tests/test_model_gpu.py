@@ -508,6 +508,46 @@ def test_data_parallel_equivalence_full_size():
     assert rel_l2(g_all, g_mean) <= 2e-3
 
 
+def test_stage1_step_with_more_than_256_patches_per_frame_vs_oracle():
+    """The geometry of `clip_l14_336` as a teacher in miniature (reference clip.py:281-295: 24 x 24 = 576 patches per frame; here 18 x 18 = 324 at
+    288 / 16 for both models): frames of more than 256 positions go through the 1024-thread form of the mask kernels, the teacher's 325-token
+    sequences and the student's 2 x 81 visible tokens through the tiled attention kernels.  Loss and every gradient against the oracle."""
+    from functools import partial
+    from unite_amd.clip import VisionTransformer
+    from unite_amd.modeling_adaptation import AdaptationVisionTransformer
+    from unite_amd.engine_stage1 import stage1_step, StepState
+    scfg = O.StudentCfg(img_size=288, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=2, tubelet_size=1,
+                        clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=(0, 1))
+    tcfg = O.TeacherCfg(input_resolution=288, patch_size=16, width=128, layers=2, heads=2, output_dim=64, clip_return_layers=(0, 1))
+    s = AdaptationVisionTransformer(img_size=288, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2, mlp_ratio=4,
+                                    qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_frames=2, tubelet_size=1,
+                                    clip_decoder_embed_dim=128, clip_output_dim=64, clip_return_layers=[0, 1])
+    t = VisionTransformer(input_resolution=288, patch_size=16, width=128, layers=2, heads=2, output_dim=64, return_attn=True,
+                          clip_return_layers=[0, 1])
+    ssd, tsd = fill_state_dict(student_shapes(scfg), 71), fill_state_dict(teacher_shapes(tcfg), 72)
+    s.load_state_dict(ssd)
+    t.load_state_dict(tsd)
+    s, t = s.to(DEV).train(), t.to(DEV).eval()
+    B, N = 2, 324
+    vid = make_videos(B, 2, 288, 288, seed=73)
+    imp = make_importance(B * 2, N, seed=74)
+    st = StepState()
+    loss = stage1_step(s, t, vid.to(DEV), B, 0.75, 'attention', None, 'mixed', st, clip_input_resolution=288, importance=imp.to(DEV))
+    mask = O.mask_from_importance(imp, N - int(N * 0.75), B)
+    assert torch.equal(st.mask.view(B, -1).cpu().bool(), mask)
+    ssd_g = {k: v.clone().requires_grad_(True) for k, v in ssd.items()}
+    ref, _, _, _ = O.stage1_loss(ssd_g, tsd, vid, mask, scfg, tcfg)
+    assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item()), (loss.item(), ref.item())
+    loss.backward()
+    ref.backward()
+    for k, p in s.named_parameters():
+        assert rel_l2(p.grad.cpu(), ssd_g[k].grad) <= 5e-2, k
+    # the attention-guided sampler itself at this frame size: exact counts per frame from the teacher's own CLS attention
+    st2 = StepState()
+    stage1_step(s, t, vid.to(DEV), B, 0.75, 'attention', None, 'mixed', st2, clip_input_resolution=288)
+    assert (~st2.mask.view(B * 2, N).cpu().bool()).sum(1).tolist() == [N - int(N * 0.75)] * (B * 2)
+
+
 @pytest.mark.parametrize("which", ["source", "target"])
 def test_stage1_loss_data_slices_vs_oracle(which):
     """clip_loss_data = 'source' / 'target' (run_stage1.py:418-427: the distillation loss over the first n_source clips of the mixed

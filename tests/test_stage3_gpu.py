@@ -40,7 +40,7 @@ def build():
 def test_greedy_masks_kernel_vs_oracle():
     from unite_amd import ops
     g = torch.Generator().manual_seed(3)
-    for BT, N, ratio, k in ((6, 16, 0.75, 2), (16, 196, 0.8, 2), (4, 196, 0.5, 2), (3, 49, 0.8, 3)):
+    for BT, N, ratio, k in ((6, 16, 0.75, 2), (16, 196, 0.8, 2), (4, 196, 0.5, 2), (3, 49, 0.8, 3), (5, 576, 0.8, 2), (2, 1024, 0.75, 4)):
         attn = torch.rand(BT, N, generator=g)
         ref = O.get_greedy_masks(attn, ratio, k)                       # (k, BT, N) True = masked
         n_vis = N - int(N * ratio)

@@ -9,7 +9,7 @@ The nn modules only hold parameters; the forward is a fixed launch schedule over
 The last block's head-averaged attention map (clip.py:95-96) is never materialised: only its CLS row is computed.
 
 Built for head_dim 64: clip_b16 (patch 16) and clip_l14 (patch 14: the 588-wide im2col rows and conv1 rows are zero-padded
-to K = 592 so they stay 16-byte multiples).  Frames of up to 256 patches (+CLS): 224 @ 16, 196 @ 14 (SURVEY 8d cfg 4/5).
+to K = 592 so they stay 16-byte multiples).  Frames of up to 1024 patches (+CLS): 224 @ 16, 196 @ 14 (SURVEY 8d cfg 4/5), 336 @ 14 (clip_l14_336).
 """
 from __future__ import annotations
 

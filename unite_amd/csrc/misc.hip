@@ -198,14 +198,17 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-// one workgroup (256 threads) per frame row; N <= 256.  keys in LDS; rank by counting; ascending compaction by scan.
-__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+// one workgroup per frame row, one thread per position: 256 threads for N <= 256 (224 @ 16, 196 @ 14), 1024 for N <= 1024 (CLIP-L/14 @ 336: 576
+// patches).  keys in LDS; rank by counting; ascending compaction by scan.
+constexpr int MASK_NMAX = 1024;
+inline int mask_threads(int N) { return N <= 256 ? 256 : 1024; }
+__global__ __launch_bounds__(1024) void mask_sample_kernel(const float* __restrict__ weights, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                           const int64_t* __restrict__ importance,
                                                           const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask,
                                                           int32_t* __restrict__ vis_tokens, int32_t* __restrict__ vis_rows_cls, int BT, int N,
                                                           int n_vis) {
-    __shared__ float key[256];
-    __shared__ int flag[256];
+    __shared__ float key[MASK_NMAX];
+    __shared__ int flag[MASK_NMAX];
     const int bt = blockIdx.x, j = threadIdx.x;
     int visible = 0;
     if (mask_in) {
@@ -269,11 +272,11 @@ __global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __re
 // ------------------------------------------------------------------------------------ stage 3: greedy committee masks
 // utils.get_greedy_masks (reference src/utils.py:89-120): per frame sort the attention descending; committee member i keeps
 // ranks i, i+k, i+2k, ... (its first n_vis of them).  One workgroup per frame, rank by counting (ties: lower index first).
-__global__ __launch_bounds__(256) void greedy_masks_kernel(const float* __restrict__ weights, int k, uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(1024) void greedy_masks_kernel(const float* __restrict__ weights, int k, uint8_t* __restrict__ mask,
                                                            int32_t* __restrict__ vis_tokens, int32_t* __restrict__ vis_rows_cls, int BT, int N,
                                                            int n_vis) {
-    __shared__ float key[256];
-    __shared__ int member[256];
+    __shared__ float key[MASK_NMAX];
+    __shared__ int member[MASK_NMAX];
     const int bt = blockIdx.x, j = threadIdx.x;
     const float w = (j < N) ? weights[(size_t)bt * N + j] : -INFINITY;
     key[j] = w;
@@ -764,8 +767,8 @@ extern "C" int unite_crop_resize_u8(const uint8_t* frames, const int32_t* boxes_
 
 extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                  int32_t BT, int32_t N, int32_t n_vis, void* stream) {
-    if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, seed, (const uint64_t*)nullptr,
+    if (!weights || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > MASK_NMAX || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(mask_threads(N)), 0, (hipStream_t)stream, weights, seed, (const uint64_t*)nullptr,
                        (const int64_t*)nullptr, (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -773,8 +776,8 @@ extern "C" int unite_mask_sample(const float* weights, uint64_t seed, uint8_t* m
 
 extern "C" int unite_mask_sample_dev(const float* weights, const uint64_t* seed_dev, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                      int32_t BT, int32_t N, int32_t n_vis, void* stream) {
-    if (!weights || !seed_dev || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, 0ull, seed_dev, (const int64_t*)nullptr,
+    if (!weights || !seed_dev || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > MASK_NMAX || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(mask_threads(N)), 0, (hipStream_t)stream, weights, 0ull, seed_dev, (const int64_t*)nullptr,
                        (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -799,8 +802,8 @@ extern "C" int unite_drop_path_scales_dev(const float* keep, const uint64_t* see
 
 extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls,
                                           int32_t BT, int32_t N, int32_t n_vis, void* stream) {
-    if (!importance || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr, importance,
+    if (!importance || !mask || !vis_tokens || BT <= 0 || N <= 0 || N > MASK_NMAX || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(mask_threads(N)), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr, importance,
                        (const uint8_t*)nullptr, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -808,8 +811,8 @@ extern "C" int unite_mask_from_importance(const int64_t* importance, uint8_t* ma
 
 extern "C" int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls, int32_t BT, int32_t N,
                                     int32_t n_vis, void* stream) {
-    if (!mask || !vis_tokens || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr,
+    if (!mask || !vis_tokens || BT <= 0 || N <= 0 || N > MASK_NMAX || n_vis <= 0 || n_vis > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(mask_sample_kernel, dim3(BT), dim3(mask_threads(N)), 0, (hipStream_t)stream, (const float*)nullptr, 0ull, (const uint64_t*)nullptr,
                        (const int64_t*)nullptr, mask, (uint8_t*)nullptr, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -817,8 +820,8 @@ extern "C" int unite_mask_to_tokens(const uint8_t* mask, int32_t* vis_tokens, in
 
 extern "C" int unite_greedy_masks(const float* weights, int32_t k, uint8_t* mask, int32_t* vis_tokens, int32_t* vis_rows_cls, int32_t BT,
                                   int32_t N, int32_t n_vis, void* stream) {
-    if (!weights || !mask || !vis_tokens || k <= 0 || BT <= 0 || N <= 0 || N > 256 || n_vis <= 0 || (int64_t)n_vis * k > N) return UNITE_EINVAL;
-    hipLaunchKernelGGL(greedy_masks_kernel, dim3(BT), dim3(256), 0, (hipStream_t)stream, weights, k, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
+    if (!weights || !mask || !vis_tokens || k <= 0 || BT <= 0 || N <= 0 || N > MASK_NMAX || n_vis <= 0 || (int64_t)n_vis * k > N) return UNITE_EINVAL;
+    hipLaunchKernelGGL(greedy_masks_kernel, dim3(BT), dim3(mask_threads(N)), 0, (hipStream_t)stream, weights, k, mask, vis_tokens, vis_rows_cls, BT, N, n_vis);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
