@@ -65,6 +65,18 @@ def main():
         random.seed(3000 + seed)
         draws = [[int(v) for v in crop_size(self, (im_w, im_h))] for _ in range(6)]
         out["crop_boxes"].append(dict(seed=3000 + seed, im_w=im_w, im_h=im_h, input_size=size, fix_crop=fix_crop, more_fix_crop=more, draws=draws))
+    # the loader-side mask generators (src/datasets/masking_generator.py: numpy only, so the module itself is loaded from its file)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_masking_generator", os.path.join(REF, "src/datasets/masking_generator.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    out["masks"] = []
+    for seed, (kind, size, ratio) in enumerate([("tube", (8, 14, 14), 0.8), ("tube", (2, 2, 2), 0.5), ("tube", (4, 6, 6), 0.75),
+                                                 ("random", (8, 14, 14), 0.8), ("random", (2, 3, 3), 0.5)]):
+        gen = (mg.TubeMaskingGenerator if kind == "tube" else mg.RandomMaskingGenerator)(size, ratio)
+        np.random.seed(4000 + seed)
+        draws = ["".join("1" if v else "0" for v in gen()) for _ in range(3)]         # one character per token, 1 = masked
+        out["masks"].append(dict(seed=4000 + seed, kind=kind, input_size=list(size), mask_ratio=ratio, draws=draws))
     with open(os.path.join(OUT, "sampling.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out)[:600])

@@ -238,3 +238,66 @@ def test_pil_resize_oracle_vs_pillow():
         OW, OH = int(rng.choice([224, 112, 37])), int(rng.choice([224, 112, 37]))
         ref = np.asarray(PIL_Image.fromarray(img).crop((x0, y0, x0 + w, y0 + h)).resize((OW, OH), PIL_Image.BILINEAR))
         assert np.array_equal(ref, crop_resize_bilinear(img, (x0, y0, w, h), (OH, OW)))
+
+
+def test_loader_mask_generators_vs_reference_golden(golden_dir):
+    """TubeMaskingGenerator / RandomMaskingGenerator (src/datasets/masking_generator.py, loaded from the reference file by
+    oracle/make_golden_sampling.py): the same masks from the same numpy seed, draw after draw."""
+    import json
+    import numpy as np
+    from unite_amd.datasets import TubeMaskingGenerator, RandomMaskingGenerator
+    cases = json.load(open(os.path.join(golden_dir, "sampling.json")))["masks"]
+    assert {c["kind"] for c in cases} == {"tube", "random"}
+    for c in cases:
+        gen = (TubeMaskingGenerator if c["kind"] == "tube" else RandomMaskingGenerator)(tuple(c["input_size"]), c["mask_ratio"])
+        np.random.seed(c["seed"])
+        for want in c["draws"]:
+            got = gen()
+            assert "".join("1" if v else "0" for v in got) == want
+            if c["kind"] == "tube":
+                T, per = c["input_size"][0], c["input_size"][1] * c["input_size"][2]
+                assert (got.reshape(T, per) == got[:per]).all() and got[:per].sum() == int(c["mask_ratio"] * per)
+
+
+def test_video_mae_dataset_draws_and_reads(tmp_path):
+    """unite_amd.datasets.VideoMAE over .npy videos: annotation parsing (mae.py:229-251), the frame numbers of a sample equal
+    frame_id_list(sample_train_indices(...)) on the same numpy stream (pinned to the reference by sampling.json), the crop box and flip come
+    from the `random` stream in the reference's order (crop first, then one random.random() whether or not flipping is on), an unreadable
+    clip is replaced by another one, and the sample carries the raw frames of exactly those numbers."""
+    import random
+    import types
+    import numpy as np
+    from unite_amd import data as D
+    from unite_amd.datasets import VideoMAE, DeviceAugmentationForVideoMAE, read_annotations
+    rng = np.random.RandomState(0)
+    sizes = [(40, 48, 64), (25, 36, 50), (9, 40, 40)]
+    lines = []
+    for i, (F, H, W) in enumerate(sizes):
+        np.save(tmp_path / f"v{i}.npy", rng.randint(0, 256, size=(F, H, W, 3), dtype=np.uint8))
+        lines.append(f"v{i}.npy {i % 2}")
+    lines.append("missing.npy 1")
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+    assert read_annotations(str(tmp_path / "train.txt")) == [("v0.npy", 0), ("v1.npy", 1), ("v2.npy", 0), ("missing.npy", 1)]
+    with pytest.raises(RuntimeError):
+        read_annotations(str(tmp_path / "nope.txt"))
+    args = types.SimpleNamespace(input_size=32, mask_type="tube", mask_ratio=0.75, window_size=(8, 2, 2), color_jitter=0.0, flip=True)
+    ds = VideoMAE(None, str(tmp_path / "train.txt"), prefix=str(tmp_path), num_segments=8, new_length=8, new_step=1,
+                  transform=DeviceAugmentationForVideoMAE(args), video_loader=True, use_decord=True)
+    assert len(ds) == 4 and ds.new_length == 8 and ds.skip_length == 1
+    for index, (F, H, W) in enumerate(sizes):
+        np.random.seed(50 + index)
+        random.seed(60 + index)
+        frames, box, flip, mask, target = ds[index]
+        np.random.seed(50 + index)
+        random.seed(60 + index)
+        idx, skip = D.sample_train_indices(F, 8, 1, 1, False)
+        ids = D.frame_id_list(F, idx, skip, 1, 1)
+        want = np.load(tmp_path / f"v{index}.npy")[ids]
+        assert frames.dtype == torch.uint8 and tuple(frames.shape) == (8, H, W, 3) and np.array_equal(frames.numpy(), want)
+        assert box == D.MultiScaleCrop(32)(W, H) and flip == (random.random() < 0.5)
+        assert mask.shape == (32,) and mask.sum() == 8 * 3 and target == index % 2
+        x0, y0, w, h = box
+        assert 0 <= x0 and x0 + w <= W and 0 <= y0 and y0 + h <= H
+    random.seed(3)
+    frames, _, _, _, target = ds[3]                       # 'missing.npy' cannot be read: another clip takes its place (mae.py:206-209)
+    assert tuple(frames.shape)[0] == 8 and target in (0, 1)

@@ -125,3 +125,73 @@ def test_run_stage3_synthetic(tmp_path):
     assert not torch.equal(ck["encoder.blocks.0.attn.qkv.weight"], init["encoder.blocks.0.attn.qkv.weight"])
     head = torch.load(out / "src_classifier_latest.pth", map_location="cpu", weights_only=True)
     assert set(head) == {"weight", "bias"} and head["weight"].shape == (5, 768)
+
+
+def _write_videos(root, n, seed):
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    lines = []
+    for i in range(n):
+        F, H, W = int(rng.randint(12, 40)), int(rng.choice([240, 256, 270])), int(rng.choice([320, 340, 256]))
+        np.save(root / f"clip{seed}_{i}.npy", rng.randint(0, 256, size=(F, H, W, 3), dtype=np.uint8))
+        lines.append(f"clip{seed}_{i}.npy {i % 4}")
+    ann = root / f"list{seed}.txt"
+    ann.write_text("\n".join(lines) + "\n")
+    return ann
+
+
+def test_device_loader_batches_equal_the_cpu_pipeline(tmp_path):
+    """unite_amd.datasets end to end on .npy videos of different sizes: every batch of the DeviceLoader equals, BIT FOR BIT, what the
+    reference's per-clip CPU pipeline produces from the same draws -- crop + Pillow-bilinear resize (oracle/pil_resize.py, pinned on Pillow),
+    flip, /255, normalise, (C,T,H,W) (build.py:32-54, mae.py:217-219) -- and carries the tube masks and labels of its samples."""
+    import random
+    import types
+    import numpy as np
+    from oracle.pil_resize import crop_resize_bilinear
+    from unite_amd.datasets import build_pretraining_dataset, DeviceLoader
+    ann = _write_videos(tmp_path, 6, 1)
+    args = types.SimpleNamespace(input_size=224, mask_type="tube", mask_ratio=0.8, window_size=(8, 14, 14), color_jitter=0.0, flip=True,
+                                 prefix=str(tmp_path), split=" ", num_segments=8, num_frames=8, umt_step=1, use_decord=True, num_sample=1)
+    ds = build_pretraining_dataset(args, str(ann))
+    dev = torch.device("cuda:0")
+    loader = DeviceLoader(ds, 3, dev, sampler=None, num_workers=0, drop_last=True)
+    assert len(loader) == 2
+    np.random.seed(11)
+    random.seed(12)
+    got = [(v.clone().cpu(), m.clone(), t.clone()) for v, m, t in loader]
+    np.random.seed(11)
+    random.seed(12)
+    from oracle import umt_oracle as O
+    from unite_amd.data import IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+    for bi in range(2):
+        videos, masks, targets = got[bi]
+        assert tuple(videos.shape) == (3, 3, 8, 224, 224) and tuple(masks.shape) == (3, 1568) and targets.tolist() == [(3 * bi + j) % 4 for j in range(3)]
+        for j in range(3):
+            frames, box, flip, mask, _ = ds[3 * bi + j]                   # the same draws again, in the same order
+            clip = np.stack([crop_resize_bilinear(f, box, (224, 224)) for f in frames.numpy()])        # (T,224,224,3) uint8
+            ref = O.clip_to_tensor(torch.from_numpy(clip)[None], IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD,
+                                   torch.tensor([1 if flip else 0], dtype=torch.uint8))[0]            # flip, /255, normalise, (C,T,H,W)
+            assert torch.equal(videos[j], ref), (bi, j, float((videos[j] - ref).abs().max()))
+            assert np.array_equal(masks[j].numpy(), mask)
+
+
+@pytest.mark.timeout(600)
+def test_run_stage1_on_npy_videos_with_a_target_domain(tmp_path):
+    """``python -m unite_amd.run_stage1`` WITHOUT --synthetic: source and target lists of .npy videos through unite_amd.datasets
+    (run_stage1.py:654-745: the smaller target list is repeated to the source's length, both loaders step together, B_s + B_t clips per step,
+    lr scaled by the doubled batch), two loader workers, attention masks from the teacher."""
+    src, tgt = _write_videos(tmp_path, 8, 2), _write_videos(tmp_path, 3, 3)
+    cfg = tmp_path / "stage1.yaml"
+    cfg.write_text(yaml.safe_dump(dict(
+        model="adaptation_umt_base_patch16_224", num_frames=8, tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+        clip_return_layers=[6, 7, 8, 9, 10, 11], clip_teacher="clip_b16", clip_return_attn=True, clip_loss_data="mixed", mask_type="attention",
+        mask_ratio=0.8, drop_path=0.1, opt="adamw", opt_betas=[0.9, 0.95], lr=1.5e-4, warmup_epochs=0, epochs=1, batch_size=2, log_freq=1,
+        use_cls_token=False, save_ckpt_freq=1, ann_file_train=str(src), ann_file_train_target=str(tgt), prefix=str(tmp_path), split=" ",
+        num_segments=8, num_workers=2, flip=True, input_size=224)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, "-m", "unite_amd.run_stage1", "--config", str(cfg), "--output_dir", str(out), "--batch_size", "2", "--seed", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Repeating target dataset 3 times" in r.stdout and "Batch size = 4" in r.stdout and "Number of training steps per epoch = 4" in r.stdout
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert len(log) == 1 and 0.5 < log[0]["train_loss"] < 2.5 and log[0]["train_grad_norm"] > 0

@@ -18,10 +18,13 @@ IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
 
 
 class ClipToTensor:
-    """callable: uint8 (B,T,H,W,3) on the device (+ optional per-clip flip flags) -> f32 (B,3,T,H,W); output buffer reused."""
+    """callable: uint8 (B,T,H,W,3) on the device (+ optional per-clip flip flags) -> f32 (B,3,T,H,W).  Every call returns a NEW tensor
+    unless ``reuse_output``: with the teacher one batch ahead the following batch is transformed (on the teacher's stream) while the
+    student may still be reading this one, so a loader must not hand out the same buffer twice."""
 
     def __init__(self, mean: Sequence[float] = IMAGENET_DEFAULT_MEAN, std: Sequence[float] = IMAGENET_DEFAULT_STD, flip_prob: float = 0.0,
-                 seed: int = 0):
+                 seed: int = 0, reuse_output: bool = False):
+        self.reuse_output = reuse_output
         self.mean, self.std, self.flip_prob = tuple(mean), tuple(std), float(flip_prob)
         self._gen: Optional[torch.Generator] = None
         self._seed = seed
@@ -36,6 +39,9 @@ class ClipToTensor:
                 self._gen = torch.Generator(device=frames.device)
                 self._gen.manual_seed(self._seed)
             flip = (torch.rand(B, device=frames.device, generator=self._gen) < self.flip_prob).to(torch.uint8)
+        if not self.reuse_output:
+            return ops.clip_u8_to_f32(frames.contiguous(), torch.empty(B, 3, T, H, W, dtype=torch.float32, device=frames.device), self.mean,
+                                      self.std, flip)
         if self._out is None or tuple(self._out.shape) != (B, 3, T, H, W):
             self._out = torch.empty(B, 3, T, H, W, dtype=torch.float32, device=frames.device)
         return ops.clip_u8_to_f32(frames.contiguous(), self._out, self.mean, self.std, flip)

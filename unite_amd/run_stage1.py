@@ -59,6 +59,36 @@ def get_model(args):
         clip_return_layers=args.clip_return_layers, clip_student_return_interval=args.clip_student_return_interval, use_cls_token=args.use_cls_token)
 
 
+def real_loaders(args, device):
+    """run_stage1.py:654-745: source (and target) training clips through unite_amd.datasets -- frame numbers, crop boxes, flips and masks are
+    drawn in the workers like the reference draws them, the pixels are cropped / resized / normalised on the GPU.  Source and target are
+    repeated so that both loaders have the same number of steps.  (The reference also builds validation / test sets here, :658-659, which
+    stage 1 only hands to the missing src/knn.py: not built.)"""
+    from .data import DistributedSampler
+    from .datasets import build_pretraining_dataset, DeviceLoader
+    args.window_size = (args.num_frames // args.tubelet_size, args.input_size // 16, args.input_size // 16)       # (:769, before the model exists)
+    world, rank = utils.get_world_size(), utils.get_rank()
+
+    def loader(dataset, repetitions):
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, repetitions=repetitions)
+        kw = dict(persistent_workers=True) if args.num_workers > 0 else {}
+        return DeviceLoader(dataset, args.batch_size, device, sampler=sampler, num_workers=args.num_workers, drop_last=True,
+                            worker_init_fn=utils.seed_worker, **kw)
+
+    dataset_train = build_pretraining_dataset(args, args.ann_file_train, fraction=args.train_fraction)
+    train_rep, target_loader = args.train_repetitions, None
+    if args.ann_file_train_target:
+        dataset_target = build_pretraining_dataset(args, args.ann_file_train_target)
+        if len(dataset_target) < len(dataset_train):
+            target_rep = int(np.ceil(len(dataset_train) / len(dataset_target)))
+            print("Repeating target dataset %d times" % target_rep)
+        else:
+            target_rep, train_rep = 1, int(np.ceil(len(dataset_target) / len(dataset_train)))
+            print("Repeating source dataset %d times" % train_rep)
+        target_loader = loader(dataset_target, target_rep)
+    return loader(dataset_train, train_rep), target_loader
+
+
 def main(args):
     utils.init_distributed_mode(args)
     device = torch.device(args.device)
@@ -69,11 +99,11 @@ def main(args):
         os.makedirs(args.output_dir, exist_ok=True)
         with open(os.path.join(args.output_dir, "config.yaml"), "w") as f:
             yaml.dump(vars(args), f, default_flow_style=False)
-    if not args.synthetic:
-        raise NotImplementedError("the decord / PIL dataset stack of the reference (src/datasets) is not part of this build: run with --synthetic, "
-                                  "or hand your own loaders to unite_amd.engine_stage1.train_one_epoch")
-    data_loader_train = SyntheticClips(args.synthetic_steps, args.batch_size, args.num_frames, args.input_size, args.nb_classes, device, seed)
-    data_loader_train_target = None                                        # a second domain would double the batch (:796)
+    if args.synthetic:
+        data_loader_train = SyntheticClips(args.synthetic_steps, args.batch_size, args.num_frames, args.input_size, args.nb_classes, device, seed)
+        data_loader_train_target = None                                    # a second domain would double the batch (:796)
+    else:
+        data_loader_train, data_loader_train_target = real_loaders(args, device)
     num_training_steps_per_epoch = len(data_loader_train)
 
     model = get_model(args)
