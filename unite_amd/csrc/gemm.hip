@@ -48,6 +48,7 @@ struct Params {
     int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
     float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
+    int32_t separate_reduce;      // split-K: the slices only write their slabs (and row-sum slabs); splitk_finish_kernel sums them afterwards
     int32_t group_rows;           // deep kernels: tiles run column-major inside groups of this many tile rows (<= 1: plain row-major order), so
                                   // that the workgroups resident on an XCD share few A panels AND few B panels of its 4-MiB L2
 };
@@ -379,7 +380,11 @@ __device__ __forceinline__ void rowsum_mfma(f32x4& racc, const bf16x8 (&af)[MT][
         }
 }
 
-template <int HALF, bool TA, bool TB>
+// WG: the weight-gradient features -- 1: row sums of op(A) (rowsum_a_out); 2: + the in-launch split-K reduction.  A template parameter, not run-time
+// flags: the extra accumulator, the one-hot fragment and the values the reduction keeps alive cost the 256^2 kernel 16 registers per lane (232 -> 248) -- with 232 a CU that holds a GEMM workgroup still has 48
+// registers per SIMD lane free, enough for a wave of the streaming kernels (LayerNorm, reductions) of another stream to run beside it; with
+// 248 it has not, and the overlapped step was 0.3-0.4 ms slower although every kernel timed alone was unchanged (round 3).
+template <int HALF, bool TA, bool TB, int WG = 0>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32;
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const int arow = wm * (HALF / 2), bcol = wn * 32;
     // row sums of op(A): the workgroups of column tile 0 only; the (A half, k-step) pairs of a K-tile are dealt over the waves of a row
     // group (HALF 128: four waves, one pair each; HALF 64: two waves, one half each), +4 MFMAs per K-tile and wave
-    const bool rs_on = p.ngroups == 1 && g.rowsum_a_out != nullptr && n0 == 0;
+    const bool rs_on = WG >= 1 && p.ngroups == 1 && g.rowsum_a_out != nullptr && n0 == 0;
     const int rs_h = WN == 4 ? (wn >> 1) : wn, rs_ks = WN == 4 ? (1 << (wn & 1)) : 3;
     f32x4 racc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nk; ++t) {
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma16(af[i][ks], b0f[j][ks], acc[0][i][0][j]);
-        if (rs_on && rs_h == 0) rowsum_mfma<MT>(racc, af, rs_ks, lane);
+        if constexpr (WG >= 1) { if (rs_on && rs_h == 0) rowsum_mfma<MT>(racc, af, rs_ks, lane); }
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 2: quadrant (0,1); needs B1
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma16(af[i][ks], b1f[j][ks], acc[1][i][1][j]);
-        if (rs_on && rs_h == 1) rowsum_mfma<MT>(racc, af, rs_ks, lane);
+        if constexpr (WG >= 1) { if (rs_on && rs_h == 1) rowsum_mfma<MT>(racc, af, rs_ks, lane); }
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 4: quadrant (1,0); operands already in registers
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     }
     // ---- row sums of op(A): the waves' partial vectors meet in LDS (k-step slots summed in a fixed order)
     const int rz_lo = g.rowsum_zero_lo, rz_hi = g.rowsum_zero_hi;
-    if (rs_on) {
+    if (WG >= 1 && rs_on) {
         float* rl = (float*)smem;                     // [2][TILE]: the epilogue image is dead behind its last barrier
         const int slot = WN == 4 ? (wn & 1) : 0;
         if (c16 < MT) {
@@ -625,7 +630,9 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         }
     }
     // ---- split-K: the slice of this tile that arrives last adds up the slabs (slice order: bitwise reproducible) and writes the tile
+    if constexpr (WG < 2) return;      // (a split launch of these forms is always followed by splitk_finish_kernel)
     if (p.splitk > 1) {
+        if (p.separate_reduce) return;
         if (!arrive_last<false>(p.counters + tile, (uint32_t)p.splitk, (volatile uint32_t*)smem)) return;      // slabs are written through
         const size_t mn = (size_t)gM * gN;
         const int S = p.splitk;
@@ -905,6 +912,37 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const Params p) {
     }
 }
 
+// Split-K, second launch (separate_reduce): out[m,n] (+)= sum_s slab[s][m,n] and rowsum_out[m] (+)= sum_s rowsum_slab[s][m], slice order.
+// A wide HBM-bound pass over S * M * N floats: used where one tile's slabs are too much for its last workgroup to add up on its own (256^2
+// tiles: S x 256 KiB read serially while the CU is held) -- the in-launch form is the same sum in the same order, so both are bit-identical.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, const float* __restrict__ rowsum_slab, int splitk, int M,
+                                                            int N, float* __restrict__ out, int ldc, int accumulate,
+                                                            float* __restrict__ rowsum_out, int rs_accumulate, int rz_lo, int rz_hi) {
+    const size_t n4 = (size_t)N / 4, total = (size_t)M * n4, mn = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / n4, c = (i % n4) * 4;
+        f32x4 a = *(const f32x4*)(slab + m * N + c);
+        for (int s = 1; s < splitk; ++s) {
+            const f32x4 b = *(const f32x4*)(slab + (size_t)s * mn + m * N + c);
+            a = (f32x4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+        }
+        float* op = out + m * ldc + c;
+        if (accumulate) {
+            const f32x4 o = *(const f32x4*)op;
+            a = (f32x4){a[0] + o[0], a[1] + o[1], a[2] + o[2], a[3] + o[3]};
+        }
+        *(f32x4*)op = a;
+    }
+    if (rowsum_out) {
+        for (int gm = blockIdx.x * 256 + threadIdx.x; gm < M; gm += gridDim.x * 256) {
+            float v = rowsum_slab[gm];
+            for (int sl = 1; sl < splitk; ++sl) v += rowsum_slab[(size_t)sl * M + gm];
+            if (gm >= rz_lo && gm < rz_hi) v = 0.f;
+            rowsum_out[gm] = rs_accumulate ? rowsum_out[gm] + v : v;
+        }
+    }
+}
+
 // colsum_out[n] (+)= sum over tile rows of the per-tile column sums the deep kernels' epilogue left (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
                                                           int accumulate) {
@@ -945,6 +983,12 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
     const int tiles[4] = {0, ((M + 127) / 128) * ((N + 127) / 128), ((M + 255) / 256) * ((N + 255) / 256), ((M + 127) / 128) * ((N + 255) / 256)};
     const int slots[4] = {0, 512, 256, 512};
     double cc[4] = {0, 1.006, 1.51, 1.58}, ee[4] = {0, 4.4, 9.8, 9.0};
+    // Cost model of products that split K.  2 (default): generic constants, the slabs streamed once more by a second launch.  3: constants fitted on
+    // stand-alone sweeps of the weight-gradient layout with the in-launch reduction's serial tail (tools/wgrad_time.py).  Model 3 predicts the
+    // stand-alone launch better and gives the SLOWER step (20.60 vs 20.44 ms, same call: it trades CU time of the side stream's launches for
+    // latency nobody waits for); UNITE_PLAN_MODEL=3 keeps it for A/B runs.
+    static const int model = getenv("UNITE_PLAN_MODEL") ? atoi(getenv("UNITE_PLAN_MODEL")) : 2;
+    if (model == 2) tt = false;
     if (tt) { cc[1] = 1.15; cc[2] = 1.64; }
     const int kt = (K + BK - 1) / BK;
     Plan best = {1, 1, 1e30};
@@ -958,12 +1002,13 @@ inline Plan plan_gemm(int M, int N, int K, bool can_split, size_t ws_bytes, int 
             const double rounds = (double)((tiles[kind] * S + slots[kind] - 1) / slots[kind]);
             const double c_eff = (tt && kind == 1 && tiles[kind] * S <= 256) ? 0.76 : cc[kind];      // a 128^2 workgroup alone on its CU
             double cost = rounds * (kts * c_eff + ee[kind]);
-            if (S > 1) cost += splitk_tail_us(kind, S);
+            const double stream_us = (double)S * M * N * 8.0 / 5.0e6;       // slab write + read at ~5 TB/s
+            if (S > 1) cost += model == 2 ? 3.0 + stream_us : splitk_tail_us(kind, S);
             // work_weight > 0: the launch shares the GPU with an independent stream (teacher one batch ahead), so what it costs the step is
             // less its own latency than the CU time it takes: workgroups x time each, over the resident slots (+ the reducing workgroups' tails)
             if (work_weight > 0.0) {
                 double work = (double)tiles[kind] * S * (kts * cc[kind] + ee[kind]) / slots[kind];      // CU time at full occupancy
-                if (S > 1) work += (double)tiles[kind] * splitk_tail_us(kind, S) / slots[kind];
+                if (S > 1) work += model == 2 ? stream_us : (double)tiles[kind] * splitk_tail_us(kind, S) / slots[kind];
                 cost = (1.0 - work_weight) * cost + work_weight * work;
             }
             if (cost < best.cost - 1e-9) best = {kind, S, cost};
@@ -1189,8 +1234,18 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         p.counters = (uint32_t*)g.workspace;
         p.rowsum_slab = (float*)((char*)g.workspace + UNITE_WS_HEADER_BYTES);
         p.slab = (float*)((char*)g.workspace + ws_head);
+        // who adds the slabs up (UNITE_SPLITK_SEPARATE): 1 (default) a second launch, splitk_finish_kernel; 0 the last slice of every tile inside the
+        // launch; 2 the launch itself for 128^2 tiles and a second launch for 256^2 ones, whose last workgroup would read S x 256 KiB on its own.
+        // Same sums in the same order either way.  In the step the three are within noise of each other (21.24 / 21.29 / 21.25 ms, same call); the
+        // second launch is the default because the kernel form without the reduction code needs fewer registers (see gemm_deep_kernel)
+        static const int sep_env = getenv("UNITE_SPLITK_SEPARATE") ? atoi(getenv("UNITE_SPLITK_SEPARATE")) : 1;
+        p.separate_reduce = sep_env == 1 || (sep_env == 2 && kind == 2);
     }
     const int nb = tiles * p.splitk;
+    // kernel form: 0 plain, 1 with the row sums compiled in, 2 with the in-launch reduction too (weight-gradient layout only; elsewhere a split
+    // product falls back to the second launch)
+    if (p.splitk > 1 && !p.separate_reduce && !(g.trans_a && g.trans_b)) p.separate_reduce = 1;
+    const int wgf = (p.splitk > 1 && !p.separate_reduce) ? 2 : (want_rowsum ? 1 : 0);
     {
         static const int gr_env = getenv("UNITE_GEMM_GROUP_ROWS") ? atoi(getenv("UNITE_GEMM_GROUP_ROWS")) : -1;
         p.group_rows = gr_env >= 0 ? gr_env : 0;
@@ -1215,20 +1270,37 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     } else if (kind == 2) {
         static bool lds_ok = false;
         if (!lds_ok) {
-            const void* ks[4] = {(const void*)gemm_deep_kernel<128, false, false>, (const void*)gemm_deep_kernel<128, false, true>,
-                                 (const void*)gemm_deep_kernel<128, true, false>, (const void*)gemm_deep_kernel<128, true, true>};
+            const void* ks[9] = {(const void*)gemm_deep_kernel<128, false, false>, (const void*)gemm_deep_kernel<128, false, true>,
+                                 (const void*)gemm_deep_kernel<128, true, false>, (const void*)gemm_deep_kernel<128, true, true>,
+                                 (const void*)gemm_deep_kernel<128, false, false, 1>, (const void*)gemm_deep_kernel<128, false, true, 1>,
+                                 (const void*)gemm_deep_kernel<128, true, false, 1>, (const void*)gemm_deep_kernel<128, true, true, 1>,
+                                 (const void*)gemm_deep_kernel<128, true, true, 2>};
             for (const void* k : ks) {
                 hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
                 if (e != hipSuccess) return (int)e;
             }
             lds_ok = true;
         }
-        if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        if (wgf == 2) {       // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
+            hipLaunchKernelGGL((gemm_deep_kernel<128, true, true, 2>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        } else if (wgf == 1) {
+            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, true, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, true, false, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+            else hipLaunchKernelGGL((gemm_deep_kernel<128, true, true, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
+        } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
         else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
         else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, true, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
         else hipLaunchKernelGGL((gemm_deep_kernel<128, true, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
     } else if (kind == 1) {
-        if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        if (wgf == 2) {       // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
+            hipLaunchKernelGGL((gemm_deep_kernel<64, true, true, 2>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        } else if (wgf == 1) {
+            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+            else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+        } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
         else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
         else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
         else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
@@ -1236,6 +1308,12 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
+    if (p.splitk > 1 && p.separate_reduce) {
+        const size_t total4 = (size_t)g.M * g.N / 4;
+        const unsigned grid = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, s, (const float*)p.slab, (const float*)p.rowsum_slab, p.splitk, g.M, g.N,
+                           (float*)g.out, g.ldc, g.accumulate, g.rowsum_a_out, g.rowsum_accumulate, g.rowsum_zero_lo, g.rowsum_zero_hi);
+    }
     if (want_colsum) {
         const int tile_m = kind == 2 ? 256 : 128;
         hipLaunchKernelGGL(colsum_rows_kernel, dim3((g.N + 63) / 64), dim3(256), 0, s, (const float*)p.colsum_partial, (g.M + tile_m - 1) / tile_m,

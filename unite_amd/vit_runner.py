@@ -80,6 +80,7 @@ class ViTRunner:
         # planner weight of the weight-gradient GEMMs (None: whatever the step runs under).  They sit on a side stream off the critical chain, so
         # CU time, not latency, is what they cost an overlapped step: UNITE_WGRAD_SHARING pins the weight for A/B runs
         self.wgrad_sharing = float(os.environ["UNITE_WGRAD_SHARING"]) if "UNITE_WGRAD_SHARING" in os.environ else None
+        self.wgrad_rowsum = os.environ.get("UNITE_WGRAD_ROWSUM", "1") != "0"      # bias gradients beside the weight-gradient products (0: separate column-sum kernels)
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
         self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
@@ -229,6 +230,7 @@ class ViTRunner:
         lnws = ws.bytes_("ln.ws", ops.layernorm_bwd_workspace(M, max(D, 1)))
         nside = self.wgrad_streams if (dx.is_cuda and self.wgrad_stream) else 1
         gws_k = [ws.bytes_("gemm.ws" if k == 0 else f"gemm.ws.{k}", SPLITK_WS_BYTES) for k in range(nside)]      # split-K slabs: one set per stream
+        csws_k = [ws.bytes_(f"cs.ws.{k}", ops.colsum_workspace(M, max(Hd, 3 * D))) for k in range(nside)] if not self.wgrad_rowsum else None
         gcws = ws.bytes_("gemm.cs.ws", ops.gemm_colsum_workspace(M, Hd))
         # Weight-gradient GEMMs and bias column sums are off the critical path (nothing in the backward chain reads them): they
         # run on a side HIP stream behind events, concurrently with the next dgrad GEMM / LayerNorm backward / attention backward
@@ -298,6 +300,9 @@ class ViTRunner:
                 # the fc1 bias gradient = column sums of dz = row sums of this product's A operand (dz^T): taken from the A tiles in LDS
                 if self.fused_colsum:
                     ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+                elif not self.wgrad_rowsum:
+                    ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+                    ops.colsum(dz, w["g:mlp.fc1.bias"], csws_k[k], accumulate=acc)
                 else:
                     ops.gemm(dz, s["h2"], w["g:mlp.fc1.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k],
                              rowsum_out=w["g:mlp.fc1.bias"], rowsum_accumulate=acc)
@@ -323,6 +328,10 @@ class ViTRunner:
             ops.gemm(dqkv, w["attn.qkv.weight"], dh1, trans_b=True)
 
             def qkv_wgrads(k, dqkv=dqkv, w=w, s=s):
+                if not self.wgrad_rowsum:
+                    ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k])
+                    ops.colsum(dqkv, w["g:qkv_bias"], csws_k[k], accumulate=acc, zero_range=(D, 2 * D))
+                    return
                 ops.gemm(dqkv, s["h1"], w["g:attn.qkv.weight"], trans_a=True, trans_b=True, accumulate=acc, workspace=gws_k[k],
                          rowsum_out=w["g:qkv_bias"], rowsum_accumulate=acc, rowsum_zero_range=(D, 2 * D))     # (dq_bias, 0, dv_bias)
             on_side(qkv_wgrads, 3, i)
