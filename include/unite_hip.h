@@ -69,8 +69,9 @@ typedef struct unite_gemm_args {
     void* out_bf16_copy; int32_t ld_copy;
     void* workspace; int64_t workspace_bytes;   /* optional scratch (16-byte aligned): lets short-and-wide products with a plain
                                                    f32 output (weight gradients) run split-K through f32 slabs [S][M][N],
-                                                   summed in a fixed order (bitwise reproducible) by the LAST slice of a tile to
-                                                   finish, inside the same launch; NULL = never split.  Layout: a header of
+                                                   summed in a fixed order (bitwise reproducible) by a second launch on the same
+                                                   stream (default) or, with UNITE_SPLITK_SEPARATE=0, by the LAST slice of a tile to
+                                                   finish inside the same launch; NULL = never split.  Layout: a header of
                                                    UNITE_WS_HEADER_BYTES (arrival counters) that must be ZERO before the first
                                                    call and is left zero by every call, then the slabs.  One workspace per
                                                    stream: two launches in flight must not share one. */
