@@ -8,6 +8,7 @@ from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["GPU_MAX_HW_QUEUES"] = "4"      # two ranks share the one GPU here: keep the default number of hardware queues (unite_amd/__init__.py)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -62,3 +62,21 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     assert rel_l2(r0["s2.grad"], r0["s2.full_grad"]) <= 2e-3
     assert r0["s2.launched"] == r1["s2.launched"] > 0
     assert abs(r0["s2.gn"] - r0["s2.full_grad"].norm().item()) <= 2e-3 * r0["s2.full_grad"].norm().item()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_path_one_rank(tmp_path):
+    """The reducer's RCCL path on the one GPU of a test box (tests/_ddp_rccl_worker.py): backend 'nccl', one rank, collectives forced.
+    Three optimisation steps under the wrapper -- with the AdamW of each bucket behind its all-reduce, and with the single launch -- leave
+    bit for bit the parameters, gradients and gradient norms of the unwrapped run, and the collectives were really issued."""
+    out = tmp_path / "rccl.pt"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_rccl_worker.py"), str(_free_port()), str(out)], cwd=ROOT,
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = torch.load(out, weights_only=True)
+    assert res["backend"] == "nccl"
+    p0, g0, n0, _ = res["plain"]
+    for key in ("ddp", "ddp_bucket"):
+        p, g, n, launched = res[key]
+        assert launched >= 3 * 4, launched                      # several buckets per step, three steps
+        assert torch.equal(p, p0) and torch.equal(g, g0) and n == n0, key

@@ -48,6 +48,9 @@ class GradReducer:
         self.grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # UNITE_DDP_FORCE_COLLECTIVES=1: issue the bucket collectives even in a one-rank group (a one-GPU box can then run the whole RCCL path --
+        # side stream, completion events, ncclAvg all-reduce per bucket, join -- as a rehearsal; the values are unchanged by a one-rank mean)
+        self.multi = self.world > 1 or (dist.is_initialized() and os.environ.get("UNITE_DDP_FORCE_COLLECTIVES", "0") == "1")
         # The all-reduce of whatever completes LAST cannot hide under any backward work (nothing is left to compute): the layers
         # that finish last (at most `tail_bytes` of gradients, at least one layer) get a bucket of their own, so that everything
         # before them is already being reduced while they are still in their backward.
@@ -84,7 +87,7 @@ class GradReducer:
         # torch.distributed's nccl backend -- the same RCCL underneath, without the process-group layer per collective.  Opt-in: its
         # multi-rank path has not run on hardware yet (one GPU per box here; tests/test_comm_gpu.py covers the one-rank communicator).
         self.comm = None
-        if self.use_stream and self.world > 1 and self.native_avg and os.environ.get("UNITE_COMM_NATIVE", "0") == "1":
+        if self.use_stream and self.multi and self.native_avg and os.environ.get("UNITE_COMM_NATIVE", "0") == "1":
             self.comm = native_comm(group)
         self._pending: List[set] = []
         self._events: List[list] = []
@@ -121,7 +124,7 @@ class GradReducer:
         i = self.tag_bucket.get(tag)
         if i is None:
             return
-        if self.use_stream and self.world > 1:
+        if self.use_stream and self.multi:
             if events is None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -132,7 +135,7 @@ class GradReducer:
             self._launch(i)
 
     def _launch(self, i):
-        if self.world == 1:
+        if not self.multi:
             if self.after_bucket is not None:      # one rank: nothing to reduce, the bucket is final as it stands
                 self.after_bucket(self.buckets[i]["lo"], self.buckets[i]["hi"])
             return
@@ -168,7 +171,7 @@ class GradReducer:
         for i, p in enumerate(self._pending):
             if p:            # a layer never reported (e.g. unused parameters): reduce what is there
                 self._pending[i] = set()
-                if self.use_stream and self.world > 1:
+                if self.use_stream and self.multi:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream())
                     self._events[i].append(ev)
@@ -212,7 +215,8 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         rt = module.runtime()
         self.rt = rt
-        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        forced = os.environ.get("UNITE_DDP_FORCE_COLLECTIVES", "0") == "1"         # one-rank rehearsal of the collective path (GradReducer)
+        if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or forced):
             dist.broadcast(rt.fp.param, src=0, group=process_group)      # run_stage1.py:809 broadcasts rank 0's weights
             rt.fp.sync_shadow()
         # every runtime lists its own layers in backward-completion order (stage 1/3 student: decoders, norm, blocks, patch
