@@ -4,6 +4,7 @@ what is compared is the kernel's arithmetic, not the rounding of its inputs.
 Tolerances: integer-valued GEMM data is bit exact; otherwise fp32-accumulate vs fp32 reference,
 |d| <= 2e-2 * scale for bf16 outputs (8 mantissa bits) and 1e-4 for f32 outputs."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -859,3 +860,17 @@ def test_token_mean_and_softmax_ce(ops):
     ops.softmax_ce(logits.detach().to(DEV), labels.to(DEV), ls, dl, row_weight=w.to(DEV), grad_scale=0.25)
     torch.testing.assert_close(ls.cpu()[0], ce.detach(), atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(dl.cpu(), logits.grad, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.timeout(600)
+def test_split_k_reduced_inside_the_launch_gives_the_same_results():
+    """UNITE_SPLITK_SEPARATE=0: the slice of a tile that finishes last adds the slabs (and the per-slice bias row sums) inside the GEMM launch
+    (common.h::arrive_last: write-through slabs, one agent-scope counter per tile) instead of the default second launch.  The library reads
+    the switch once per process, so the split-K and row-sum tests above run again in a child process with it set: integer data, bit-exact."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNITE_SPLITK_SEPARATE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "splitk or rowsum or weight_gradient"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
