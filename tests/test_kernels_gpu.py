@@ -874,3 +874,17 @@ def test_split_k_reduced_inside_the_launch_gives_the_same_results():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=550)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_grouped_tile_order_is_a_bijection():
+    """UNITE_GEMM_GROUP_ROWS=3: the tile kernels walk tile rows in groups of three, column-major inside a group (on by itself only for very deep
+    products).  Every GEMM test of this file -- ragged tile counts, both tile sizes, split-K, every epilogue -- runs again in a child process
+    with the order forced: a tile visited twice or not at all shows up as a wrong product."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNITE_GEMM_GROUP_ROWS="3", UNITE_GEMM_PP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "gemm and not persistent"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

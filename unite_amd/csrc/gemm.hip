@@ -1247,8 +1247,13 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     if (p.splitk > 1 && !p.separate_reduce && !(g.trans_a && g.trans_b)) p.separate_reduce = 1;
     const int wgf = (p.splitk > 1 && !p.separate_reduce) ? 2 : (want_rowsum ? 1 : 0);
     {
+        // tile rows walked in groups (column-major inside a group): pays where ONE tile row's A panel is a large part of an XCD's 4-MiB L2, i.e.
+        // for very deep products (8192^3: 1117 -> 1367 TF/s with groups of four); at the depths of the training step (K <= 3072) it changes
+        // neither kernel nor step time, so it is off there.  UNITE_GEMM_GROUP_ROWS=r forces r (0: never).
         static const int gr_env = getenv("UNITE_GEMM_GROUP_ROWS") ? atoi(getenv("UNITE_GEMM_GROUP_ROWS")) : -1;
-        p.group_rows = gr_env >= 0 ? gr_env : 0;
+        const int tile_e = kind == 2 ? 256 : 128;
+        const bool deep = g.K >= 4096 && (g.M + tile_e - 1) / tile_e >= 8 && (g.N + tile_e - 1) / tile_e >= 8;
+        p.group_rows = gr_env >= 0 ? gr_env : (deep ? 4 : 0);
     }
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
