@@ -226,6 +226,13 @@ class FusedAdamW(torch.optim.Optimizer):
                        self._step, grad_scale=grad_scale)
         self._open["done"].append((lo, hi))
 
+    def abort_step(self):
+        """drop a step opened by begin_step() whose backward did not complete: ranges already updated stay updated (their gradients were
+        final), the step count goes back so that the next begin_step() does not skip a bias-correction step"""
+        if getattr(self, "_open", None) is not None:
+            self._open = None
+            self._step -= 1
+
     def _finish_open_step(self, grad_scale=None):
         done = sorted(self._open["done"])
         pos = 0

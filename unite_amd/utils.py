@@ -51,14 +51,17 @@ class NativeScalerWithGradNormCount:
             reducer.after_bucket = optimizer.step_range
         try:
             loss.backward(create_graph=create_graph)
+            if not update_grad:
+                return None
+            if reducer is not None:
+                reducer.finish()                      # join the gradient all-reduce (side stream) before reading grads
+        except BaseException:
+            if per_bucket:
+                optimizer.abort_step()                # a backward that raised leaves no half-open optimizer step behind
+            raise
         finally:
-            if per_bucket and not update_grad:
+            if per_bucket:
                 reducer.after_bucket = None
-        if not update_grad:
-            return None
-        if reducer is not None:
-            reducer.finish()                          # join the gradient all-reduce (side stream) before reading grads
-            reducer.after_bucket = None
         flat = getattr(optimizer, "_flat", None)
         if flat is None:
             raise RuntimeError("optimizer is not a unite_amd FusedAdamW bound to a flat parameter buffer")
