@@ -218,6 +218,7 @@ class VideoMAE(torch.utils.data.Dataset):
         return D.frame_id_list(duration, idx, skip, self.skip_length, self.new_step)
 
     def __getitem__(self, index):
+        failures = 0
         while True:
             name, target = self.clips[index]
             try:
@@ -226,6 +227,9 @@ class VideoMAE(torch.utils.data.Dataset):
                 break
             except Exception as e:                                     # noqa: BLE001 -- any unreadable clip is replaced, as the reference does
                 print("Failed to load video from {} with error {}".format(name, e))
+                failures += 1
+                if failures >= 64:                                     # (the reference would spin for ever on a list with nothing readable)
+                    raise RuntimeError(f"64 clips in a row could not be read (last: {name}): check prefix / video_ext / the reader") from e
                 index = random.randint(0, len(self.clips) - 1)
         frames = torch.from_numpy(np.ascontiguousarray(frames))
         box, flip, mask = self.transform.draw(frames.shape[2], frames.shape[1])
