@@ -195,3 +195,19 @@ def test_run_stage1_on_npy_videos_with_a_target_domain(tmp_path):
     assert "Repeating target dataset 3 times" in r.stdout and "Batch size = 4" in r.stdout and "Number of training steps per epoch = 4" in r.stdout
     log = [json.loads(l) for l in open(out / "log.txt")]
     assert len(log) == 1 and 0.5 < log[0]["train_loss"] < 2.5 and log[0]["train_grad_norm"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_data_parallel_flow_rehearsed_with_one_rank(tmp_path):
+    """bench.py as the driver launches it, except that the process group has ONE rank (UNITE_DDP_FORCE_COLLECTIVES=1): backend nccl = RCCL, the
+    student under the data-parallel wrapper, bucket all-reduces on the reducer's stream, barrier + synchronize around the timed steps.  stdout
+    must be exactly the JSON record (RCCL prints a banner at communicator creation: it belongs on stderr) and the loss must be a trained one."""
+    env = dict(os.environ, UNITE_DDP_FORCE_COLLECTIVES="1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "4", "--no-cpu-baseline",
+                        "--no-roofline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["unit"] == "clips/s" and rec["value"] > 0 and 0.0 < rec["final_loss"] < 4.0
+    assert rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
