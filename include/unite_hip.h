@@ -120,6 +120,11 @@ int unite_gemm_get_policy(void);
  * not depend on it beyond the f32 summation order of split-K.  UNITE_GEMM_PLAN_WORK in the environment pins the value. */
 int unite_gemm_set_sharing(float work_weight);
 float unite_gemm_get_sharing(void);
+/* The planner's choice for a product with a plain f32 output that may split K through `slab_bytes` of workspace (beyond the header and the
+ * row-sum area): *kind = 1 (128 x 128 tiles), 2 (256 x 256) or 3 (128 x 256), *splitk = number of K slices.  `sharing` as plan_sharing,
+ * `rowsum` != 0 if rowsum_a_out will be set (tile kernels with the row sums only).  Host arithmetic only: callable without a GPU. */
+int unite_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b, float sharing, int64_t slab_bytes, int32_t rowsum,
+                    int32_t* kind, int32_t* splitk);
 
 /* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
  * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117

@@ -58,6 +58,7 @@ SIGNATURES = {
     "unite_gemm_get_policy": (c_i, []),
     "unite_gemm_set_sharing": (c_i, [C.c_float]),
     "unite_gemm_get_sharing": (C.c_float, []),
+    "unite_gemm_plan": (c_i, [c_i, c_i, c_i, c_i, c_i, C.c_float, c_i64, c_i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "unite_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "unite_gemm_bf16_grouped": (c_i, [C.POINTER(GemmArgs), c_i, c_p]),
     "unite_prof_enable": (c_i, [c_i, c_i]),

@@ -1135,6 +1135,19 @@ extern "C" int unite_gemm_set_sharing(float work_weight) {
     return UNITE_OK;
 }
 extern "C" float unite_gemm_get_sharing(void) { return (float)g_plan_work; }
+
+// What the planner would choose for a product that may split K (plain f32 output, a workspace of `slab_bytes` for the slabs): tile kernel
+// (1: 128^2, 2: 256^2, 3: 128 x 256) and split factor.  Host arithmetic only -- no device is touched -- so the planner can be inspected and
+// pinned by tests on a box without a GPU.
+extern "C" int unite_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b, float sharing, int64_t slab_bytes, int32_t rowsum,
+                               int32_t* kind, int32_t* splitk) {
+    if (M <= 0 || N <= 0 || K <= 0 || !kind || !splitk || !(sharing >= 0.f && sharing <= 1.f) || slab_bytes < 0) return UNITE_EINVAL;
+    const bool deep_only = rowsum != 0;
+    const Plan plan = plan_gemm(M, N, K, slab_bytes > 0, (size_t)slab_bytes, 0, deep_only, (double)sharing, trans_a && trans_b);
+    *kind = plan.kind;
+    *splitk = plan.splitk;
+    return UNITE_OK;
+}
 int unite_gemm_pp_supported(const unite_gemm_args& g);
 int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_bytes, hipStream_t s);
 
