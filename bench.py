@@ -6,8 +6,9 @@ A "step" is one full stage-1 iteration on a batch of B=32 synthetic 8-frame 224x
 320 visible tokens -> ViT-B/16 student forward + decoders + UMT loss -> backward -> gradient all-reduce (N>1) ->
 global grad-norm -> AdamW.  Inputs are resident in HBM before the timed region; nothing is skipped inside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts the N ranks itself, see self_start)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config 3|4|5 [--steps K] [--warmup W]       (one GPU: BASELINE configs[2..4] -- stage 2, stage 3, ViT-L stage 1)
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernels (bf16 MFMA GEMM family + fused teacher kernel): algorithmic FLOPs / launch time,
@@ -35,14 +36,61 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+
+def self_start(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (RANK unset): start the N ranks ourselves, BEFORE this process has made
+    any HIP call, as fresh children -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>` (the reference's launch line, stage1.sh:15-17) -- relay rank 0's one JSON line on stdout (anything else the
+    children write to stdout goes to stderr) and exit with the launcher's return code.  Returns None when there is nothing to start."""
+    import socket
+    import subprocess
+    n = 1
+    for i, tok in enumerate(argv):
+        if tok == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    if n <= 1 or "RANK" in os.environ:
+        return None
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    record = None
+    for line in child.stdout:
+        try:
+            rec = json.loads(line)
+            if isinstance(rec, dict) and "metric" in rec:
+                record = line.strip()
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(line)
+    rc = child.wait()
+    if record is not None:
+        print(record, flush=True)
+    return rc if rc != 0 or record is not None else 1
+
+
+if __name__ == "__main__":
+    _rc = self_start(sys.argv[1:])
+    if _rc is not None:
+        raise SystemExit(_rc)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# Before the first HIP call (unite_amd/__init__.py makes the same setting, but this file touches the GPU before it imports the package): the
+# Before the first HIP call (`import unite_amd` applies the same rule, but this file touches the GPU before it imports the package): the
 # step's four busy streams plus RCCL's do not fit HIP's default four hardware queues -- with a process group alive the teacher's stream shares
-# the student's queue and the step takes 24.2 instead of 20.4 ms.  Only where every rank has a GPU of its own.
-if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) <= max(torch.cuda.device_count(), 1):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the student's queue and the step takes 24.2 instead of 20.4 ms.  Decided from the environment alone (unite_amd/hwqueues.py: no torch.cuda call).
+from unite_amd.hwqueues import apply as _apply_hw_queues  # noqa: E402
+_HWQ = _apply_hw_queues()
 
 PEAK_BF16 = 2.5e15            # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 GF_STUDENT, GF_TEACHER = 179.7e9, 282.5e9     # algorithmic FLOPs per clip, BASELINE.md section 2
@@ -109,6 +157,35 @@ def cpu_baseline(seconds_budget=30.0):
     return {"value": round(value, 3), "unit": "clips/s", "cores": threads, "kind": "port", "sample": sample}
 
 
+def other_config(a):
+    """--config 3 | 4 | 5: the per-GPU step of BASELINE configs[2..4] on one GPU, in this file's record format (no roofline pass: the
+    kernels are those of the headline step, profiled there; mfma_frac = clips/s x algorithmic GFLOP per clip / 2.5 PF/s)"""
+    import importlib.util
+    if a.gpus != 1:
+        raise SystemExit("--config 3 / 4 / 5 time the per-GPU step on ONE GPU")
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)                                   # stdout carries the record only
+    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    name = {3: "stage2", 4: "stage3", 5: "vitl"}[a.config]
+    steps, warmup = (a.steps, a.warmup)
+    r = bc.run(name, None, "clip_l14", steps, warmup)
+    unit = "clip pairs/s" if a.config == 4 else "clips/s"
+    out = {"metric": {3: "stage-2 train clips/sec (ViT-B/16, 16fx224^2, 8 classes)", 4: "stage-3 train (src, tgt) clip pairs/sec (ViT-B/16 + CLIP-L/14 mask teacher, 8fx224^2)",
+                      5: "stage-1 train clips/sec (ViT-L/16 + CLIP-L/14, 16fx224^2)"}[a.config],
+           "value": r["clips_per_s"], "unit": unit, "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": r["workload"] + f" (BASELINE configs[{a.config - 1}], per-GPU shapes on one GPU)", "global_batch": r["batch"], "parallelism": "dp1"},
+           "final_loss": r["loss"], "final_grad_norm": r["grad_norm"], "ranks_seen": 1, "hw_queues": _HWQ,
+           "roofline": {"bound": "mfma", "achieved": round(r["mfma_frac"] * PEAK_BF16 / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                        "frac": r["mfma_frac"], "traffic": None, "gflop_per_unit": r["gflop_per_clip"],
+                        "note": "whole step: units/s x algorithmic GFLOP per unit (SURVEY 8d) over the bf16 MFMA peak; per-kernel figures: the headline config's roofline"},
+           "hbm_peak_GiB": r["hbm_peak_GiB"]}
+    os.write(record_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,7 +202,13 @@ def main():
                     help="1: the frozen teacher runs one batch ahead of the student on its own stream (engine_stage1.TeacherAhead, what "
                          "train_one_epoch does by default); 0: teacher and student of a step strictly one after the other")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) | gloo (rehearsal of the N>1 flow on one GPU)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[] by 1-based position: 2 (default) the headline stage-1 step, B = 32; 3 stage-2 fine-tune step "
+                         "(ViT-B/16, 16 f, B = 16); 4 stage-3 collaborative step (ViT-B/16 + CLIP-L/14 mask teacher, 16 src + 16 tgt); "
+                         "5 stage-1 ViT-L/16 + CLIP-L/14 (16 f, B = 8).  3-5: one GPU, the per-GPU shapes of those configs (tools/bench_configs.py)")
     a = ap.parse_args()
+    if a.config != 2:
+        return other_config(a)
     # stdout carries exactly ONE line, the JSON record: whatever libraries print there (RCCL's version banner at communicator creation, gloo's
     # connection messages) is sent to stderr by pointing file descriptor 1 at it for the whole run; the record is written to the saved descriptor
     sys.stdout.flush()
@@ -411,6 +494,7 @@ def main():
                           "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05",
                           "launch": "hip_graph" if graphed is not None else "eager",
                           "schedule": "teacher one batch ahead of the student (own stream)" if ahead is not None else "teacher then student"},
+               "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "hw_queues": _HWQ,
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                "host_ms_per_step_unblocked": None if host_ms is None else round(host_ms, 3)}

@@ -82,7 +82,10 @@ typedef struct unite_gemm_args {
                                                    not read again for it.  Per-tile partial sums go through `workspace`
                                                    (>= unite_gemm_colsum_workspace(M, N) bytes), summed in a fixed order. */
     /* ---- ABI 2: everything below may be left zero (a zeroed struct asks for the process-wide defaults) ---- */
-    int32_t plan_flags;                         /* bit 0: plan_persistent is a per-call hint, bit 1: plan_sharing is */
+    int32_t plan_flags;                         /* bit 0: plan_persistent is a per-call hint, bit 1: plan_sharing is, bit 2: bit 3 is the
+                                                   main-loop schedule of the tile kernels for THIS launch (0: fragment reads at the head
+                                                   of each phase, 1: software-pipelined reads between the MFMAs; default UNITE_GEMM_SCHED,
+                                                   1) -- same products bit for bit, an A/B switch */
     int32_t plan_persistent;                    /* as unite_gemm_set_policy, for THIS launch only */
     float   plan_sharing;                       /* as unite_gemm_set_sharing, for THIS launch only */
     int32_t residual_bf16;                      /* `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream) */

@@ -211,3 +211,19 @@ def test_bench_data_parallel_flow_rehearsed_with_one_rank(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["unit"] == "clips/s" and rec["value"] > 0 and 0.0 < rec["final_loss"] < 4.0
     assert rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun around it (how a driver's `--gpus N` leg may call it): bench.py starts the two ranks itself
+    before touching the GPU (self_start: fresh children under torch.distributed.run on 127.0.0.1), relays rank 0's ONE JSON line and returns the
+    launcher's code.  Two ranks share the one GPU of the test box over gloo, so the hardware-queue rule must leave HIP's default pool alone."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GPU_MAX_HW_QUEUES")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--no-cpu-baseline", "--no-roofline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and 0.0 < rec["final_loss"] < 4.0 and "share" in rec["hw_queues"]

@@ -10,21 +10,10 @@ All device arithmetic is in unite_amd/lib/libunite_hip.so (C ABI: include/unite_
 """
 import os as _os
 
-# HIP maps its streams onto a pool of hardware queues (4 by default).  A training step here keeps four streams busy at once (student, its
-# weight gradients, the teacher one batch ahead, the gradient reducer) and RCCL adds its own: with four queues the teacher's stream lands
-# on the student's queue as soon as a process group exists, the two phases run one after the other again and a step takes 24.2 instead of
-# 20.4 ms (measured with a one-rank RCCL group).  Has to be in the environment before the first HIP call of the process.
-# Only where every rank of the node has a GPU of its own: two processes sharing one GPU (the gloo rehearsals of the tests) with eight queues
-# each oversubscribe the hardware queues, which the driver then time-slices -- a two-rank rehearsal went from 64 s to > 200 s.
+# HIP's hardware-queue pool is sized before the first HIP call of the process, from the environment alone (hwqueues.py states the rule and why)
+from .hwqueues import apply as _apply_hw_queues  # noqa: E402
 
-
-def _own_gpu_per_rank() -> bool:
-    import torch
-    return int(_os.environ.get("LOCAL_WORLD_SIZE", "1")) <= max(torch.cuda.device_count(), 1)      # (counting devices does not start HIP)
-
-
-if _own_gpu_per_rank():
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_apply_hw_queues()
 
 from .registry import create_model, register_model, list_models  # noqa: F401,E402
 from . import modeling_adaptation  # noqa: F401,E402  (registers the student factories)

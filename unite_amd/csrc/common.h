@@ -122,6 +122,13 @@ __device__ __forceinline__ bf16x8 lds_read_b128_raw(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return __builtin_bit_cast(bf16x8, v);
 }
+// the transposing read in the same untracked form, LDS byte address + immediate offset
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16_raw_off(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(LDS_AS const char*)p; }
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

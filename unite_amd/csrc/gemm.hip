@@ -380,11 +380,52 @@ __device__ __forceinline__ void rowsum_mfma(f32x4& racc, const bf16x8 (&af)[MT][
         }
 }
 
+// ---- software-pipelined main loop (SCHED 1): untracked fragment reads ------------------------------------------------------------
+// One reader per operand and wave: the lane's byte address inside a half-tile image for m-/n-tile 0, k-step 0.  Tile I, k-step KS and the slot
+// are immediate offsets of the ds instruction; the XOR-swizzled k-strided images need one v_xor per tile instead (the tile index only flips
+// chunk bits the lane part leaves clear).  The reads are inline asm the compiler's wait-count tracking does not see: the loop that issues them
+// places every `s_waitcnt lgkmcnt(N)` by hand, N = the number of ds instructions issued AFTER the one a group of MFMAs needs (LDS returns in order).
+template <bool TR, int HALF>
+struct FragReader {
+    static constexpr int READS = TR ? 2 : 1;      // ds instructions per fragment
+    uint32_t a0, a1;
+    __device__ __forceinline__ void init(int rowbase, int lane) {      // rowbase: the wave's first row (A) / column (B) inside a half, a multiple of 32
+        const int G = lane >> 4;
+        if (!TR) {                                   // [HALF][64 k] image, chunk c of row r at c ^ (r & 7): k-step 1 flips chunk bit 2
+            a0 = (uint32_t)((rowbase + (lane & 15)) * 128 + ((G ^ (lane & 7)) << 4));
+            a1 = a0 ^ 64u;
+        } else if (HALF == 128) {                    // [64 k][128] image, 16-B chunk c of k-row k at c ^ swz256(k); k + 4 flips chunk bit 0
+            const int q = (lane >> 2) & 3, pp = lane & 3, k = 8 * G + q;
+            a0 = (uint32_t)(256 * k + ((((rowbase >> 3) + (pp >> 1)) ^ swz256(k)) << 4) + 8 * (pp & 1));
+            a1 = a0 ^ 16u;
+        } else {                                     // [64 k][64] image, 32-B chunk c of k-row k at c ^ swz128t(k) (the same for k and k + 4)
+            const int q = (lane >> 2) & 3, pp = lane & 3, k = 8 * G + q;
+            a0 = (uint32_t)(128 * k + (((rowbase >> 4) ^ swz128t(k)) << 5) + 8 * pp);
+            a1 = 0;
+        }
+    }
+    // fragment of tile I (16 rows / columns), k-step KS, from the slot at byte offset OFF of the set at LDS address `set`
+    template <int I, int KS, int OFF>
+    __device__ __forceinline__ bf16x8 read(uint32_t set) const {
+        if constexpr (!TR) {
+            return lds_read_b128_raw<OFF + I * 2048>((KS ? a1 : a0) + set);
+        } else if constexpr (HALF == 128) {
+            const uint32_t x = (a0 ^ (uint32_t)(I << 5)) + set, y = (a1 ^ (uint32_t)(I << 5)) + set;
+            return tr_join(lds_read_tr16_raw_off<OFF + KS * 8192>(x), lds_read_tr16_raw_off<OFF + KS * 8192 + 1024>(y));
+        } else {
+            const uint32_t x = (a0 ^ (uint32_t)(I << 5)) + set;
+            return tr_join(lds_read_tr16_raw_off<OFF + KS * 4096>(x), lds_read_tr16_raw_off<OFF + KS * 4096 + 512>(x));
+        }
+    }
+};
+#define UNITE_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+#define UNITE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // WG: the weight-gradient features -- 1: row sums of op(A) (rowsum_a_out); 2: + the in-launch split-K reduction.  A template parameter, not run-time
 // flags: the extra accumulator, the one-hot fragment and the values the reduction keeps alive cost the 256^2 kernel 16 registers per lane (232 -> 248) -- with 232 a CU that holds a GEMM workgroup still has 48
 // registers per SIMD lane free, enough for a wave of the streaming kernels (LayerNorm, reductions) of another stream to run beside it; with
 // 248 it has not, and the overlapped step was 0.3-0.4 ms slower although every kernel timed alone was unchanged (round 3).
-template <int HALF, bool TA, bool TB, int WG = 0>
+template <int HALF, bool TA, bool TB, int WG = 0, int SCHED = 0>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32;
@@ -460,7 +501,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 for (int j = 0; j < 2; ++j) acc[h][i][nh][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int q = 0; q < 6; ++q) issue(q);
+    for (int q = 0; q < (SCHED == 1 ? 7 : 6); ++q) issue(q);
     f32x4 bias0, bias1;
     load_bias8(g, n0 + (tid % (TILE / 8)) * 8, bias0, bias1);
 
@@ -470,6 +511,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const bool rs_on = WG >= 1 && p.ngroups == 1 && g.rowsum_a_out != nullptr && n0 == 0;
     const int rs_h = WN == 4 ? (wn >> 1) : wn, rs_ks = WN == 4 ? (1 << (wn & 1)) : 3;
     f32x4 racc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (SCHED == 0) {
     for (int t = 0; t < nk; ++t) {
         char* set = smem + (t & 1) * (4 * SLOT);
         const char* A0 = set;
@@ -550,6 +592,122 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma16(af[i][ks], b0f[j][ks], acc[1][i][0][j]);
         __builtin_amdgcn_s_setprio(0);
+    }
+    } else {
+    // ---- SCHED 1: the same quadrant walk, software-pipelined.  A phase no longer opens with its fragment reads: every fragment is read one
+    // phase EARLIER, between the MFMAs of the phase before, into registers that have just died --
+    //   P1  X(A0) Y(B0) -> acc(0,0)    reads Z <- B1                       DMA A1 (t+1)
+    //   P2  X(A0) Z(B1) -> acc(0,1)    reads X <- A1, tile by tile behind the last MFMA pair that used it     DMA A0 (t+2)
+    //   P3  X(A1) Z(B1) -> acc(1,1)    --                                  DMA B0 (t+2)
+    //   P4  X(A1) Y(B0) -> acc(1,0)    reads X <- A0', Y <- B0' of the NEXT K-tile the same way             DMA B1 (t+2)
+    // so a wave never waits for LDS latency at the head of a phase, and the reads and the two LDS-DMA issues of a phase sit between MFMA pairs
+    // instead of in front of the cluster.  Every half-tile is therefore needed one phase earlier than in SCHED 0: the DMA stream runs 7 half-tiles
+    // ahead (same eight slots: a slot is refilled two or more barriers after the phase that read it), `vmcnt(8)` + barrier in front of P1, P2 and
+    // P4 retires exactly the half-tile that phase reads (P3 reads nothing and has no barrier).  The reads are untracked asm (FragReader); the
+    // lgkmcnt numbers below are counts of ds instructions issued after the fragment a pair needs.
+    constexpr int RA = FragReader<TA, HALF>::READS, RB = FragReader<TB, HALF>::READS;
+    constexpr int SET = 4 * SLOT, OA0 = 0, OA1 = SLOT, OB0 = 2 * SLOT, OB1 = 3 * SLOT;
+    constexpr int NP = 2 * MT;                          // MFMA pairs per phase (k-step major)
+    constexpr int D0 = MT == 4 ? 2 : 0, D1 = MT == 4 ? 5 : 2;      // the pairs behind which the phase's two LDS-DMA pieces are issued
+    FragReader<TA, HALF> ra;
+    FragReader<TB, HALF> rb;
+    ra.init(arow, lane);
+    rb.init(bcol, lane);
+    const uint32_t lds0 = lds_address(smem);
+    bf16x8 X[MT][2], Y[2][2], Z[2][2];
+    // one LDS-DMA piece (i = 0, 1) of half-tile `kind` of K-tile u
+    auto piece = [&](auto kind_c, int u, int i) {
+        constexpr int kind = decltype(kind_c)::value;
+        char* set = smem + (u & 1) * SET;
+        const int k0 = k_begin + u * BK, it = wave * 2 + i;
+        if constexpr (kind == 0) stage_piece<TA, HALF>(rsA, set + OA0, it, m0, k0, gM, k_end, lda, lane);
+        else if constexpr (kind == 1) stage_piece<TB, HALF>(rsB, set + OB0, it, n0, k0, gN, k_end, ldb, lane);
+        else if constexpr (kind == 2) stage_piece<TB, HALF>(rsB, set + OB1, it, n0 + HALF, k0, gN, k_end, ldb, lane);
+        else stage_piece<TA, HALF>(rsA, set + OA1, it, m0 + HALF, k0, gM, k_end, lda, lane);
+    };
+    // X <- A0, Y <- B0 of K-tile 0, in the order P4 issues them (k-step major: X[.][ks] then Y[.][ks])
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // 14 pieces issued: A0, B0 of K-tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    static_for<0, 2>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<0, MT>([&](auto ic) { X[decltype(ic)::value][ks] = ra.template read<decltype(ic)::value, ks, OA0>(lds0); });
+        static_for<0, 2>([&](auto jc) { Y[decltype(jc)::value][ks] = rb.template read<decltype(jc)::value, ks, OB0>(lds0); });
+    });
+    UNITE_FENCE();
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t cur = lds0 + (uint32_t)((t & 1) * SET), nxt = lds0 + (uint32_t)(((t + 1) & 1) * SET);
+        // ---- P1: (0,0)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B1 of this K-tile has landed
+        __builtin_amdgcn_s_barrier();
+        UNITE_LGKM(MT * RA + 2 * RB);                      // X[.][0], Y[.][0]: only the k-step-1 fragments may still be on their way
+        UNITE_FENCE();
+        static_for<0, NP>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
+            if constexpr (pi == MT) { UNITE_LGKM(4 * RB); UNITE_FENCE(); }      // X[.][1], Y[.][1]: younger are the four Z fragments only
+            acc[0][i][0][0] = mfma16(X[i][ks], Y[0][ks], acc[0][i][0][0]);
+            acc[0][i][0][1] = mfma16(X[i][ks], Y[1][ks], acc[0][i][0][1]);
+            UNITE_FENCE();
+            if constexpr (pi == 0) {
+                Z[0][0] = rb.template read<0, 0, OB1>(cur);
+                Z[1][0] = rb.template read<1, 0, OB1>(cur);
+                Z[0][1] = rb.template read<0, 1, OB1>(cur);
+                Z[1][1] = rb.template read<1, 1, OB1>(cur);
+            }
+            if constexpr (pi == D0) piece(std::integral_constant<int, 3>{}, t + 1, 0);
+            if constexpr (pi == D1) piece(std::integral_constant<int, 3>{}, t + 1, 1);
+            UNITE_FENCE();
+        });
+        if constexpr (WG >= 1) { if (rs_on && rs_h == 0) rowsum_mfma<MT>(racc, X, rs_ks, lane); UNITE_FENCE(); }
+        // ---- P2: (0,1); X dies pair by pair and is refilled with A1
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A1 of this K-tile has landed
+        __builtin_amdgcn_s_barrier();
+        UNITE_LGKM(2 * RB);                                // Z[.][0]
+        UNITE_FENCE();
+        static_for<0, NP>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
+            if constexpr (pi == MT) { UNITE_LGKM(MT * RA); UNITE_FENCE(); }     // Z[.][1]: younger are the MT fragments read behind pairs 0 .. MT-1
+            acc[0][i][1][0] = mfma16(X[i][ks], Z[0][ks], acc[0][i][1][0]);
+            acc[0][i][1][1] = mfma16(X[i][ks], Z[1][ks], acc[0][i][1][1]);
+            UNITE_FENCE();
+            X[i][ks] = ra.template read<i, ks, OA1>(cur);
+            if constexpr (pi == D0) piece(std::integral_constant<int, 0>{}, t + 2, 0);
+            if constexpr (pi == D1) piece(std::integral_constant<int, 0>{}, t + 2, 1);
+            UNITE_FENCE();
+        });
+        // ---- P3: (1,1); no reads, no barrier
+        UNITE_LGKM(MT * RA);                               // X[.][0]
+        UNITE_FENCE();
+        static_for<0, NP>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
+            if constexpr (pi == MT) { UNITE_LGKM(0); UNITE_FENCE(); }
+            acc[1][i][1][0] = mfma16(X[i][ks], Z[0][ks], acc[1][i][1][0]);
+            acc[1][i][1][1] = mfma16(X[i][ks], Z[1][ks], acc[1][i][1][1]);
+            UNITE_FENCE();
+            if constexpr (pi == D0) piece(std::integral_constant<int, 1>{}, t + 2, 0);
+            if constexpr (pi == D1) piece(std::integral_constant<int, 1>{}, t + 2, 1);
+            if constexpr (pi == D0 || pi == D1) UNITE_FENCE();
+        });
+        if constexpr (WG >= 1) { if (rs_on && rs_h == 1) rowsum_mfma<MT>(racc, X, rs_ks, lane); UNITE_FENCE(); }
+        // ---- P4: (1,0); X and Y die pair by pair and are refilled with A0, B0 of the next K-tile
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A0, B0 of K-tile t + 1 have landed
+        __builtin_amdgcn_s_barrier();
+        static_for<0, NP>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
+            acc[1][i][0][0] = mfma16(X[i][ks], Y[0][ks], acc[1][i][0][0]);
+            acc[1][i][0][1] = mfma16(X[i][ks], Y[1][ks], acc[1][i][0][1]);
+            UNITE_FENCE();
+            X[i][ks] = ra.template read<i, ks, OA0>(nxt);
+            if constexpr (i == MT - 1) {
+                Y[0][ks] = rb.template read<0, ks, OB0>(nxt);
+                Y[1][ks] = rb.template read<1, ks, OB0>(nxt);
+            }
+            if constexpr (pi == D0) piece(std::integral_constant<int, 2>{}, t + 2, 0);
+            if constexpr (pi == D1) piece(std::integral_constant<int, 2>{}, t + 2, 1);
+            UNITE_FENCE();
+        });
+    }
+    UNITE_LGKM(0);      // the last P4 read fragments nobody uses: they must have arrived before their registers are reused
+    UNITE_FENCE();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-fill DMAs must not land in the epilogue image
     __syncthreads();
@@ -960,6 +1118,41 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
     }
 }
 
+// ---- launch of the deep tile kernels: HALF x weight-gradient form x layouts x schedule -> one instantiation
+template <int HALF, bool TA, bool TB, int WG, int SCHED>
+int launch_deep_one(int nb, hipStream_t s, const Params& p) {
+    constexpr int lds = 8 * HALF * 128;
+    auto* k = gemm_deep_kernel<HALF, TA, TB, WG, SCHED>;
+    if (lds > 64 * 1024) {      // 128 KiB of dynamic LDS needs the opt-in, once per instantiation
+        static bool ok = false;
+        if (!ok) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            ok = true;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(nb), dim3(4 * HALF), lds, s, p);
+    return UNITE_OK;
+}
+template <int HALF, int WG, int SCHED>
+int launch_deep_layout(bool ta, bool tb, int nb, hipStream_t s, const Params& p) {
+    if (!ta && !tb) return launch_deep_one<HALF, false, false, WG, SCHED>(nb, s, p);
+    if (!ta && tb) return launch_deep_one<HALF, false, true, WG, SCHED>(nb, s, p);
+    if (ta && !tb) return launch_deep_one<HALF, true, false, WG, SCHED>(nb, s, p);
+    return launch_deep_one<HALF, true, true, WG, SCHED>(nb, s, p);
+}
+template <int HALF>
+int launch_deep(int wgf, bool ta, bool tb, int sched, int nb, hipStream_t s, const Params& p) {
+    if (wgf == 2) return launch_deep_one<HALF, true, true, 2, 0>(nb, s, p);      // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
+    if (wgf == 1) return sched ? launch_deep_layout<HALF, 1, 1>(ta, tb, nb, s, p) : launch_deep_layout<HALF, 1, 0>(ta, tb, nb, s, p);
+    return sched ? launch_deep_layout<HALF, 0, 1>(ta, tb, nb, s, p) : launch_deep_layout<HALF, 0, 0>(ta, tb, nb, s, p);
+}
+// UNITE_GEMM_SCHED = 0 | 1: process default of the main-loop schedule (per call: plan_flags bits 2, 3)
+inline int g_sched_env() {
+    static const int v = getenv("UNITE_GEMM_SCHED") ? atoi(getenv("UNITE_GEMM_SCHED")) : 1;
+    return v != 0;
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Joint choice of kernel and split-K factor from a cost model fitted on MI355X (us):
@@ -1285,43 +1478,12 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
             else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_wide_kernel<true, false, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
             else hipLaunchKernelGGL((gemm_wide_kernel<true, true, false>), dim3(nb), dim3(256), WIDE_LDS, s, p);
         }
-    } else if (kind == 2) {
-        static bool lds_ok = false;
-        if (!lds_ok) {
-            const void* ks[9] = {(const void*)gemm_deep_kernel<128, false, false>, (const void*)gemm_deep_kernel<128, false, true>,
-                                 (const void*)gemm_deep_kernel<128, true, false>, (const void*)gemm_deep_kernel<128, true, true>,
-                                 (const void*)gemm_deep_kernel<128, false, false, 1>, (const void*)gemm_deep_kernel<128, false, true, 1>,
-                                 (const void*)gemm_deep_kernel<128, true, false, 1>, (const void*)gemm_deep_kernel<128, true, true, 1>,
-                                 (const void*)gemm_deep_kernel<128, true, true, 2>};
-            for (const void* k : ks) {
-                hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * 128);
-                if (e != hipSuccess) return (int)e;
-            }
-            lds_ok = true;
-        }
-        if (wgf == 2) {       // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
-            hipLaunchKernelGGL((gemm_deep_kernel<128, true, true, 2>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-        } else if (wgf == 1) {
-            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, true, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, true, false, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-            else hipLaunchKernelGGL((gemm_deep_kernel<128, true, true, 1>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-        } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-        else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, false, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-        else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<128, true, false>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-        else hipLaunchKernelGGL((gemm_deep_kernel<128, true, true>), dim3(nb), dim3(512), 8 * 128 * 128, s, p);
-    } else if (kind == 1) {
-        if (wgf == 2) {       // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
-            hipLaunchKernelGGL((gemm_deep_kernel<64, true, true, 2>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-        } else if (wgf == 1) {
-            if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-            else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-            else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-            else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true, 1>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-        } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-        else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, false, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-        else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_deep_kernel<64, true, false>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
-        else hipLaunchKernelGGL((gemm_deep_kernel<64, true, true>), dim3(nb), dim3(256), 8 * 64 * 128, s, p);
+    } else if (kind == 2 || kind == 1) {
+        // kernel form x operand layouts x main-loop schedule (0: fragment reads at the head of each phase, 1: software-pipelined, see gemm_deep_kernel)
+        const int sched = (wgf == 2) ? 0 : (g.plan_flags & 4) ? ((g.plan_flags >> 3) & 1) : g_sched_env();
+        const int rc = kind == 2 ? launch_deep<128>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p)
+                                 : launch_deep<64>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p);
+        if (rc != UNITE_OK) return rc;
     } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), dim3(nb), dim3(256), LDS_BYTES, s, p);
     else if (g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);

@@ -59,25 +59,29 @@ class _PlanHints(threading.local):
     global is written, so two host threads -- or a non-Python binder beside this one -- never see each other's choice"""
     persistent: Optional[int] = None
     sharing: Optional[float] = None
+    sched: Optional[int] = None
 
 
 _hints = _PlanHints()
 
 
 @contextlib.contextmanager
-def plan(persistent: Optional[int] = None, sharing: Optional[float] = None):
+def plan(persistent: Optional[int] = None, sharing: Optional[float] = None, sched: Optional[int] = None):
     """GEMM launches enqueued inside the block carry these hints (None: leave as is): ``persistent`` as unite_gemm_set_policy
     (0 never / 1 measured shapes / 2 whenever supported), ``sharing`` as unite_gemm_set_sharing (0 .. 1: how much the launch's CU time
-    counts against its latency -- the launches share the GPU with another stream)."""
-    before = (_hints.persistent, _hints.sharing)
+    counts against its latency -- the launches share the GPU with another stream), ``sched`` the tile kernels' main-loop schedule
+    (plan_flags bits 2 / 3: 0 reads at the head of each phase, 1 software-pipelined; an A/B switch, the products are bit-identical)."""
+    before = (_hints.persistent, _hints.sharing, _hints.sched)
     if persistent is not None:
         _hints.persistent = int(persistent)
     if sharing is not None:
         _hints.sharing = float(sharing)
+    if sched is not None:
+        _hints.sched = int(sched)
     try:
         yield
     finally:
-        _hints.persistent, _hints.sharing = before
+        _hints.persistent, _hints.sharing, _hints.sched = before
 
 
 def keep_plan(ctx) -> None:
@@ -192,6 +196,8 @@ def _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scal
     if _hints.sharing is not None:
         g.plan_flags |= 2
         g.plan_sharing = _hints.sharing
+    if _hints.sched is not None:
+        g.plan_flags |= 4 | (8 if _hints.sched else 0)
     return g
 
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import datetime
 import math
+import statistics
 import os
 import time
 from collections import defaultdict, deque
@@ -130,37 +131,43 @@ def clip_infer(model, videos, text_features):
 
 
 # ----------------------------------------------------------------------------- schedules (utils.py:646-686)
+def _warmup_ramp(base_value, niter_per_ep, warmup_epochs, start_warmup_value, warmup_steps):
+    """the linear ramp both schedules start with, and the number of iterations it stands for.  As in the reference the ramp exists only when
+    warmup_epochs > 0, while its LENGTH is warmup_steps whenever that is positive (so warmup_steps without warmup_epochs leaves a gap that the
+    length check of the caller rejects, utils.py:649-654)."""
+    n = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    ramp = np.linspace(start_warmup_value, base_value, n) if warmup_epochs > 0 else np.empty(0)
+    return ramp, n
+
+
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
-    warmup_schedule = np.array([])
-    warmup_iters = warmup_epochs * niter_per_ep
-    if warmup_steps > 0:
-        warmup_iters = warmup_steps
-    print("Set warmup steps = %d" % warmup_iters)
-    if warmup_epochs > 0:
-        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
-    iters = np.arange(epochs * niter_per_ep - warmup_iters)
-    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / (len(iters)))) for i in iters])
-    schedule = np.concatenate((warmup_schedule, schedule))
-    assert len(schedule) == epochs * niter_per_ep
-    return schedule
+    """per-iteration values: linear warm-up to base_value, then half a cosine period down to final_value (reference utils.py:646-663; pinned by
+    tests/golden/utils.npz)."""
+    total = epochs * niter_per_ep
+    ramp, n_warm = _warmup_ramp(base_value, niter_per_ep, warmup_epochs, start_warmup_value, warmup_steps)
+    print(f"Set warmup steps = {n_warm:d}")
+    n_cos = total - n_warm
+    phase = np.arange(n_cos, dtype=np.float64) / max(n_cos, 1)                      # 0 .. (n-1)/n: the last value stays above final_value
+    values = np.concatenate([ramp, final_value + 0.5 * (base_value - final_value) * (1.0 + np.cos(np.pi * phase))])
+    assert len(values) == total, (len(values), total)
+    return values
 
 
 def step_scheduler(base_value, step_fraction, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1, steps=None):
-    warmup_schedule = np.array([])
-    warmup_iters = warmup_epochs * niter_per_ep
-    if warmup_steps > 0:
-        warmup_iters = warmup_steps
-    if warmup_epochs > 0:
-        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    """constant base_value after the warm-up, or -- with `steps` (epoch numbers) -- a staircase of cumulative factors step_fraction[i] from epoch
+    steps[i] on, over the whole run and relative to 1.0 as the reference builds it (utils.py:666-686)."""
+    total = epochs * niter_per_ep
+    ramp, n_warm = _warmup_ramp(base_value, niter_per_ep, warmup_epochs, start_warmup_value, warmup_steps)
     if steps is None:
-        schedule = np.ones(epochs * niter_per_ep - warmup_iters) * base_value
+        body = np.full(total - n_warm, float(base_value))
     else:
-        schedule = np.ones(epochs * niter_per_ep)
-        for i in range(len(steps)):
-            schedule[steps[i] * niter_per_ep:] *= step_fraction[i]
-    schedule = np.concatenate((warmup_schedule, schedule))
-    assert len(schedule) == epochs * niter_per_ep
-    return schedule
+        epoch_of = np.arange(total) // niter_per_ep
+        body = np.ones(total)
+        for first_epoch, factor in zip(steps, step_fraction):
+            body = np.where(epoch_of >= first_epoch, body * factor, body)
+    values = np.concatenate([ramp, body])
+    assert len(values) == total, (len(values), total)
+    return values
 
 
 def get_greedy_masks(attn, mask_ratio, k):
@@ -177,70 +184,63 @@ def get_greedy_masks(attn, mask_ratio, k):
 
 # ----------------------------------------------------------------------------- meters (utils.py:215-423)
 class SmoothedValue(object):
+    """a series seen through a window of the last `window_size` values plus its running mean over everything (reference utils.py:215-277: same
+    properties and format fields; the window statistics are plain Python here -- nothing of this runs on the device)."""
+
     def __init__(self, window_size=20, fmt=None):
-        self.deque = deque(maxlen=window_size)
-        self.total, self.count = 0.0, 0
-        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+        self.fmt = "{median:.4f} ({global_avg:.4f})" if fmt is None else fmt
+        self.deque = deque(maxlen=window_size)          # (attribute name kept: callers of the reference read it)
+        self.count = 0
+        self.total = 0.0
 
     def update(self, value, n=1):
         self.deque.append(value)
+        self.total += n * value
         self.count += n
-        self.total += value * n
 
     def synchronize_between_processes(self):
+        """count and total summed over the ranks; the window stays local (as in the reference)"""
         if not is_dist_avail_and_initialized():
             return
-        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        pair = torch.tensor([self.count, self.total], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.barrier()
-        dist.all_reduce(t)
-        t = t.tolist()
-        self.count, self.total = int(t[0]), t[1]
+        dist.all_reduce(pair)
+        self.count, self.total = int(pair[0].item()), float(pair[1].item())
 
-    @property
-    def median(self):
-        return torch.tensor(list(self.deque)).median().item()
+    def _window(self):
+        return [float(v) for v in self.deque]
 
-    @property
-    def avg(self):
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
-
-    @property
-    def global_avg(self):
-        return self.total / max(self.count, 1)
-
-    @property
-    def max(self):
-        return max(self.deque)
-
-    @property
-    def value(self):
-        return self.deque[-1]
+    median = property(lambda self: statistics.median_low(self._window()))          # the lower middle value, as torch.median picks it
+    avg = property(lambda self: math.fsum(self._window()) / len(self.deque))
+    global_avg = property(lambda self: self.total / max(self.count, 1))
+    max = property(lambda self: max(self.deque))
+    value = property(lambda self: self.deque[-1])
 
     def __str__(self):
-        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+        fields = {name: getattr(self, name) for name in ("median", "avg", "global_avg", "max", "value") if "{" + name in self.fmt}
+        return self.fmt.format(**fields)
 
 
 class MetricLogger(object):
+    """named SmoothedValue meters, created on first update, reachable as attributes (reference utils.py:280-360)"""
+
     def __init__(self, delimiter="\t"):
-        self.meters = defaultdict(SmoothedValue)
         self.delimiter = delimiter
+        self.meters = defaultdict(SmoothedValue)
 
     def update(self, **kwargs):
-        for k, v in kwargs.items():
-            if v is None:
-                continue
-            if isinstance(v, torch.Tensor):
-                v = v.item()
-            self.meters[k].update(float(v))
+        for name, v in kwargs.items():
+            if v is not None:                      # (the reference skips None the same way: a loss that was not computed this step)
+                self.meters[name].update(float(v.item() if isinstance(v, torch.Tensor) else v))
 
     def __getattr__(self, attr):
-        if attr in self.meters:
-            return self.meters[attr]
-        raise AttributeError(attr)
+        meters = self.__dict__.get("meters", {})
+        if attr not in meters:
+            raise AttributeError(attr)
+        return meters[attr]
 
     def __str__(self):
-        return self.delimiter.join("{}: {}".format(n, str(m)) for n, m in self.meters.items())
+        return self.delimiter.join(f"{name}: {meter}" for name, meter in self.meters.items())
 
     def synchronize_between_processes(self):
         for meter in self.meters.values():
@@ -315,36 +315,29 @@ def init_distributed_mode(args):
 
 # ----------------------------------------------------------------------------- checkpoints (utils.py:689-776)
 def load_state_dict(model, state_dict, prefix='', ignore_missing="relative_position_index"):
-    """reference utils.py:554-599: non-strict recursive load with a key prefix; reports missing / unused / ignored keys."""
-    missing_keys, unexpected_keys, error_msgs = [], [], []
-    metadata = getattr(state_dict, '_metadata', None)
-    state_dict = state_dict.copy()
-    if metadata is not None:
-        state_dict._metadata = metadata
-
-    def load(module, prefix=''):
-        local_metadata = {} if metadata is None else metadata.get(prefix[:-1], {})
-        module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys, unexpected_keys, error_msgs)
-        for name, child in module._modules.items():
-            if child is not None:
-                load(child, prefix + name + '.')
-
-    load(model, prefix=prefix)
-    warn_missing_keys, ignore_missing_keys = [], []
-    for key in missing_keys:
-        if any(ig in key for ig in ignore_missing.split('|')):
-            ignore_missing_keys.append(key)
-        else:
-            warn_missing_keys.append(key)
-    if len(warn_missing_keys) > 0:
-        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, warn_missing_keys))
-    if len(unexpected_keys) > 0:
-        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected_keys))
-    if len(ignore_missing_keys) > 0:
-        print("Ignored weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, ignore_missing_keys))
-    if len(error_msgs) > 0:
-        print('\n'.join(error_msgs))
-    return warn_missing_keys, unexpected_keys        # (the bf16 shadow follows by itself: FlatParams watches tensor versions)
+    """non-strict load with a key prefix that REPORTS instead of raising (reference utils.py:554-599): every module takes what it finds under its
+    own prefix through nn.Module._load_from_state_dict; afterwards the missing keys are split into ignorable ones (a '|'-separated list of
+    substrings) and the rest, and the unused keys are listed.  Returns (missing keys that matter, unused keys)."""
+    src = state_dict.copy()
+    meta = getattr(state_dict, '_metadata', None)
+    if meta is not None:
+        src._metadata = meta
+    missing, unused, errors = [], [], []
+    for name, module in model.named_modules():                 # parents before children, the order a recursive walk visits them in
+        where = prefix + (name + '.' if name else '')
+        module._load_from_state_dict(src, where, {} if meta is None else meta.get(where[:-1], {}), True, missing, unused, errors)
+    patterns = ignore_missing.split('|')
+    ignored = [k for k in missing if any(pat in k for pat in patterns)]
+    wanted = [k for k in missing if k not in ignored]
+    cls = model.__class__.__name__
+    for keys, text in ((wanted, "Weights of {} not initialized from pretrained model: {}"),
+                       (unused, "Weights from pretrained model not used in {}: {}"),
+                       (ignored, "Ignored weights of {} not initialized from pretrained model: {}")):
+        if keys:
+            print(text.format(cls, keys))
+    if errors:
+        print('\n'.join(errors))
+    return wanted, unused        # (the bf16 shadow follows by itself: FlatParams watches tensor versions)
 
 
 def _plain(obj):
