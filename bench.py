@@ -58,6 +58,11 @@ def self_start(argv):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from unite_amd import hwqueues                 # (host logic only: importing the package makes no HIP call)
+    masked = hwqueues.mask_entries(env)
+    gpus = masked if masked is not None else hwqueues.kfd_gpu_nodes()
+    if gpus and n > gpus:                          # a rehearsal: more ranks than GPUs, so ranks share devices -- tell the hardware-queue rule
+        env.setdefault("UNITE_RANKS_SHARE_GPU", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
@@ -324,15 +329,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # diagnostic (UNITE_CLOCK_PROBE=1): a short kernel at the end of every timed step stamps {shader clock counter, 100-MHz reference counter}
+    # per XCD (unite_clock_stamp) -> "shader_clock_mhz": the clock the chip held, averaged over each step.  (A resident probe wave on its own
+    # stream -- unite_clock_probe -- is no good here: beside it the multi-stream step takes 42 instead of 20 ms.)
+    probe = None
+    if os.environ.get("UNITE_CLOCK_PROBE", "0") == "1":
+        probe = torch.zeros(a.steps + 1, 8, 2, dtype=torch.int64, device=dev)
+
     sprio = os.environ.get("UNITE_STUDENT_PRIO")
     sctx = torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(sprio))) if sprio is not None else contextlib.nullcontext()
     with sctx:
         for _ in range(a.warmup):
             loss, gn = step()
         fence()
+        if probe is not None:
+            _lib.check(_lib.load().unite_clock_stamp(probe[0].data_ptr(), torch.cuda.current_stream().cuda_stream), "unite_clock_stamp")
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for k_step in range(a.steps):
             loss, gn = step()
+            if probe is not None:
+                _lib.check(_lib.load().unite_clock_stamp(probe[k_step + 1].data_ptr(), torch.cuda.current_stream().cuda_stream), "unite_clock_stamp")
         t_enq = time.perf_counter() - t0          # the host has enqueued every launch of the timed steps (nothing synchronises inside a step)
         fence()
     dt = time.perf_counter() - t0
@@ -340,6 +356,18 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    clock = None
+    if probe is not None:
+        sm = probe.cpu().numpy().astype("float64")                         # [step boundary][XCD][{shader, reference}]
+        mhz = []
+        for x in range(8):
+            c, r = sm[:, x, 0], sm[:, x, 1]
+            ok = (r[1:] > 0) & (r[:-1] > 0) & (r[1:] > r[:-1])              # both stamps landed on this XCD
+            mhz += list(((c[1:] - c[:-1]) / (r[1:] - r[:-1]) * 100.0)[ok])
+        if mhz:
+            mhz.sort()
+            clock = {"mean": round(sum(mhz) / len(mhz), 1), "p10": round(mhz[len(mhz) // 10], 1), "median": round(mhz[len(mhz) // 2], 1),
+                     "p90": round(mhz[len(mhz) * 9 // 10], 1), "samples": len(mhz), "averaged_over": "one step, per XCD"}
     loss_v, gn_v = float(loss.item()), float(gn.item())
     # random-init student against a random-init teacher: the cosine loss starts at ~2 and can only move inside [0, 4] (run_stage1.py:431)
     if not (loss_v == loss_v and 0.0 <= loss_v <= 4.0 and gn_v == gn_v and gn_v > 0.0):
@@ -498,6 +526,8 @@ def main():
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
                "host_ms_per_step_unblocked": None if host_ms is None else round(host_ms, 3)}
+        if clock is not None:
+            out["shader_clock_mhz"] = clock
         if roof is not None:
             out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1:

@@ -132,7 +132,8 @@ int unite_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t tr
 /* `count` (1..4) independent problems with the same trans_a / trans_b in ONE launch (no split-K, workspace ignored):
  * the four weight gradients of a transformer block (dW = dY^T X with K = tokens: modeling_finetune.py:67-71,106,117
  * under autograd) fill the chip together instead of each needing split-K slabs.  Results are identical to `count`
- * single calls without a workspace (same tile kernel, same accumulation order). */
+ * single calls without a workspace (same tile kernel, same accumulation order).  The fused bias sums are NOT available here:
+ * a problem with rowsum_a_out or colsum_out set is refused with UNITE_EINVAL (they need the single-problem launch). */
 int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t count, void* stream);
 
 /* Diagnostics for bench.py's roofline leg: when enabled, every unite_gemm_bf16 launch is bracketed by two HIP events
@@ -142,6 +143,16 @@ int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t count, void* st
  * pre-activation matrix once).  Not for use under stream capture. */
 int unite_prof_enable(int32_t on, int32_t max_launches);
 int unite_prof_summary(double* total_ms, int64_t* launches, double* total_flops, double* total_bytes);
+/* Diagnostic: the shader clock the chip actually holds while other kernels run.  ONE wave (one workgroup of 64 threads, no LDS, a handful of
+ * registers) takes `samples` pairs {shader-clock counter (s_memtime), 100-MHz reference counter (s_memrealtime)}, `interval_us` apart, sleeping
+ * in between, and exits: samples_out is uint64 [samples][2] in device memory.  Launched on a stream of its own beside the work to observe; the
+ * clock over an interval is (d s_memtime / d s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  samples <= 65536,
+ * 1 <= interval_us <= 100000: the wave always exits after samples x interval_us. */
+int unite_clock_probe(uint64_t* samples_out, int32_t samples, int32_t interval_us, void* stream);
+/* The same pair taken ONCE per XCD by a short kernel in the caller's stream: out is uint64 [8][2] (XCD, {s_memtime, s_memrealtime}; an XCD no
+ * workgroup of the 64 landed on keeps its old contents).  Two stamps around a span of work give the average clock over it, per XCD -- usable
+ * inside a multi-stream step, where a resident probe wave disturbs the schedule (measured: the stage-1 step takes 42 instead of 20 ms beside it). */
+int unite_clock_stamp(uint64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the last dim (D % 4 == 0, D <= 1024), one wavefront per row, fp32 statistics.

@@ -46,8 +46,12 @@ from oracle import make_golden as MG  # noqa: E402
 from oracle.filler import fill_state_dict, make_videos  # noqa: E402
 
 NOISE = float(os.environ.get("NOISE", "0.26"))          # spread of the injected CLIP features around their common component
-SEED = int(os.environ.get('SEED', '96'))             # chosen so that every selection rule picks a proper subset somewhere (printed below)
-CLS_SCALE = float(os.environ.get('CLS_SCALE', '0.2'))       # classifier weight scale: chosen so that max-softmax-probs straddle 0.5
+# Seed and classifier scale are chosen (a search over seeds 1-40 at scales 0.3 / 0.4: the MARGINS line printed at the end, DRY=1 for the line alone) so that
+# every one of the seven selection rules picks a PROPER subset of the four target clips, the confidences fall on both sides of the 0.5 / 0.6
+# thresholds, and no decision sits close enough to its threshold for a bf16-operand logit error (measured <= 0.035) to flip it: the gaps between
+# the two largest logits are >= 0.20 (full clips) / 0.22 (masked committee), the confidences >= 0.025 from 0.5 and >= 0.05 from 0.6
+SEED = int(os.environ.get('SEED', '15'))
+CLS_SCALE = float(os.environ.get('CLS_SCALE', '0.3'))
 GRAD_KEYS = ['encoder.patch_embed.proj.weight', 'encoder.blocks.0.attn.qkv.weight', 'encoder.blocks.0.attn.q_bias', 'encoder.blocks.1.mlp.fc1.weight',
              'encoder.blocks.2.mlp.fc2.bias', 'encoder.blocks.2.norm2.weight', 'encoder.norm.weight', 'encoder.norm.bias']
 CLIP_THRESHOLD = 0.6       # args.clip_threshold of clip_matchORconf (run_stage3.py:560); `conf` / `clip_only` use the hard-wired 0.5 (:522)
@@ -181,20 +185,38 @@ def main():
         optimizer = types.SimpleNamespace(param_groups=[], zero_grad=lambda: None)
         logged.clear()
         model = Holder(student)
+        local = {}
+
+        def at_return(frame, event, arg):
+            # the step's own local variables when train_one_epoch returns (one batch per run, so they are this batch's): the per-clip selection
+            # mask, the student's predictions = pseudo-labels, their soft-max confidences and the labels the target loss was taken against
+            if event == "return" and frame.f_code.co_name == "train_one_epoch":
+                for name in ("sel_mask", "preds_full_t", "msp_t", "ce_target", "sel_mask_cons", "sel_mask_conf"):
+                    if name in frame.f_locals and torch.is_tensor(frame.f_locals[name]):
+                        local[name] = frame.f_locals[name].detach().clone()
         try:
+            sys.setprofile(at_return)
             stats = ns["train_one_epoch"](
                 model, [(videos_s, labels_s)], [(videos_t, videos_t_aug, labels_t)], optimizer, torch.device("cpu"), 0, scaler,
                 max_norm=None, log_writer=None, lr_scheduler=None, start_steps=0, lr_schedule_values=None, wd_schedule_values=None,
                 src_classifier=cls, teacher_model=teacher, clip_input_resolution=32, mask_type="attention", mask_ratio=MASK_RATIO,
                 use_wandb=True, args=args)
         finally:
+            sys.setprofile(None)
             utils_ref.get_greedy_masks, utils_ref.clip_infer = greedy, infer
         w = logged[0]
+        assert local["sel_mask"].shape == (B_T,) and local["preds_full_t"].shape == (B_T,)
+        assert abs(float(local["sel_mask"].float().mean()) - float(w["train/select_ratio"])) < 1e-9
         pre = f"{strat}."
         out.update({pre + "loss": stats["loss"], pre + "loss_s": stats["loss_class"], pre + "loss_t": stats["loss_class_t"],
                     pre + "grad_norm": float(scaler.norm), pre + "select_ratio": float(w["train/select_ratio"]),
                     pre + "logits_s": rec["logits"][0], pre + "logits_full_t": rec["logits"][1],
-                    pre + "logits_masked": rec["logits"][2].view(2, B_T, C_CLS), pre + "masks": rec["masks"]})
+                    pre + "logits_masked": rec["logits"][2].view(2, B_T, C_CLS), pre + "masks": rec["masks"],
+                    # per clip, from the reference's own locals: selected or not, the pseudo-label (the student's prediction on the full clip,
+                    # run_stage3.py:489,599-602), its confidence; and the labels of the SELECTED clips the target loss used, in clip order
+                    pre + "sel_mask": local["sel_mask"].to(torch.uint8), pre + "pseudo_labels": local["preds_full_t"].long(),
+                    pre + "msp_t": local["msp_t"].float(),
+                    pre + "ce_target": local.get("ce_target", torch.zeros(0, dtype=torch.long)).long()})
         if rec["sims"] is not None:
             out[pre + "similarities"] = rec["sims"]
         for k, p in student.named_parameters():
@@ -210,6 +232,19 @@ def main():
                   rec["sims"].argmax(-1).tolist(), "masked preds", rec["logits"][2].view(2, B_T, C_CLS).argmax(-1).tolist(), "labels_t", labels_t.tolist())
         print(f"{strat:18s} loss {stats['loss']:.6f} = src {stats['loss_class']:.6f} + tgt {stats['loss_class_t']:.6f}  "
               f"select_ratio {w['train/select_ratio']:.2f}  grad_norm {float(scaler.norm):.5f}")
+    # how far every decision of the step is from flipping (the HIP step computes the same logits from bf16 operands: measured error <= 0.035):
+    # gaps between the two largest logits of the full and the masked passes, distance of the confidences from the thresholds
+    lf, lm = out["cons.logits_full_t"], out["cons.logits_masked"]
+    top2 = lambda x: (x.topk(2, dim=-1).values[..., 0] - x.topk(2, dim=-1).values[..., 1]).min().item()
+    msp = lf.softmax(-1).max(-1).values
+    sims = out["clip_only.similarities"].max(-1).values
+    margins = {"full_top2_gap": top2(lf), "masked_top2_gap": top2(lm), "msp_to_0.5": (msp - 0.5).abs().min().item(),
+               "msp_to_clip_threshold": (msp - CLIP_THRESHOLD).abs().min().item(), "clip_msp_to_0.5": (sims - 0.5).abs().min().item(),
+               "clip_msp_to_clip_threshold": (sims - CLIP_THRESHOLD).abs().min().item()}
+    ratios = [float(out[s + ".select_ratio"]) for s in STRATEGIES]
+    print("MARGINS seed", SEED, "scale", CLS_SCALE, " ".join(f"{k}={v:.3f}" for k, v in margins.items()), "ratios", ratios)
+    if os.environ.get("DRY", "0") == "1":
+        return
     path = os.path.join(MG.OUT, "stage3_step.npz")
     np.savez_compressed(path, **MG._np(out))
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -119,3 +119,23 @@ def test_planner_choices_for_the_weight_gradients_of_the_step():
     k, s = C.c_int32(), C.c_int32()
     assert lib.unite_gemm_plan(768, 768, 10240, 1, 1, 0.8, 0, 0, C.byref(k), C.byref(s)) == 0 and s.value == 1       # no workspace: never split
     assert lib.unite_gemm_plan(768, 768, 10240, 1, 1, 1.5, slabs, 0, C.byref(k), C.byref(s)) < 0                      # weight outside [0, 1]
+
+
+def test_grouped_gemm_refuses_the_fused_bias_sums():
+    """unite_gemm_bf16_grouped runs the plain kernel form: a problem that asks for rowsum_a_out / colsum_out must be refused (UNITE_EINVAL),
+    not answered with UNITE_OK and the sums unwritten (round-3 advisor finding).  Argument checking only: no device is touched."""
+    import ctypes as C
+    from unite_amd import _lib
+    lib = _lib.load()
+
+    def problem(**extra):
+        g = _lib.GemmArgs()
+        g.M, g.N, g.K, g.trans_a, g.trans_b = 256, 256, 512, 1, 1
+        g.A, g.lda, g.B, g.ldb, g.out, g.ldc, g.out_f32 = 0x10000, 256, 0x20000, 256, 0x30000, 256, 1      # never dereferenced: refused first
+        for k, v in extra.items():
+            setattr(g, k, v)
+        return g
+    for bad in (dict(rowsum_a_out=0x40000), dict(colsum_out=0x40000)):
+        arr = (_lib.GemmArgs * 2)(problem(), problem(**bad))
+        assert lib.unite_gemm_bf16_grouped(arr, 2, None) == -1, bad
+    # (a schedule hint that is not 0 / 1 cannot be expressed: plan_flags bit 3 IS the value)

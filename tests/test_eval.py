@@ -78,3 +78,36 @@ def test_stage3_validation_on_gpu():
     stats = validation_one_epoch([(vids, vids, lab)], s, cls, torch.device("cuda"), args=args)
     assert abs(stats["loss"] - torch.nn.functional.cross_entropy(ref, lab).item()) <= 2.5e-2
     assert abs(stats["acc1"] - (ref.argmax(1) == lab).float().mean().item() * 100) < 1e-4
+
+
+@pytest.mark.gpu
+def test_stage3_final_test_on_gpu(tmp_path):
+    """run_stage3.py:927-989 + merge: the per-view lines carry encoder -> mean pool -> source classifier logits (checked against the oracle's,
+    line by line), two views per clip merge into the per-clip accuracy of the mean soft-max."""
+    import tests.test_stage3_gpu as T
+    from oracle import umt_oracle as O
+    from unite_amd.engine_stage3 import final_test
+    s, t, cls, ssd, tsd, d = T._setup(seed=1)
+    views = [d["videos_t"], d["videos_s"]]                       # two "views" (chunk 0 / 1) of four clips
+    lab = torch.tensor([2, 3, 0, 2])
+    refs = []
+    for v in views:
+        x, _ = O.student_forward(ssd, v, torch.zeros(4, 32, dtype=torch.bool), T.S3_S, clip_only=False)
+        refs.append(torch.nn.functional.linear(x.mean(1), cls.weight.detach().cpu(), cls.bias.detach().cpu()))
+    loader = [(v, lab, [f"clip{j}" for j in range(4)], torch.tensor([c] * 4), torch.tensor([0] * 4)) for c, v in enumerate(views)]
+    args = SimpleNamespace(use_cls_token=False)
+    stats = final_test(loader, s, cls, torch.device("cuda"), str(tmp_path / "0.txt"), args)
+    ref_a1 = (torch.cat(refs).argmax(1) == torch.cat([lab, lab])).float().mean().item() * 100
+    assert abs(stats["acc1"] - ref_a1) < 1e-4 and stats["loss"] > 0
+    lines = open(tmp_path / "0.txt").read().splitlines()
+    assert len(lines) == 1 + 8
+    for c in range(2):
+        for j in range(4):
+            name, _, rest = lines[1 + 4 * c + j].partition(" [")
+            vec, _, tail = rest.partition("]")
+            got = np.array([float(x) for x in vec.split(",")])
+            assert name == f"clip{j}" and tail.split() == [str(int(lab[j])), str(c), "0"]
+            np.testing.assert_allclose(got, refs[c][j].numpy(), atol=4e-2, rtol=1e-2)
+    top1, top5 = E.merge(str(tmp_path), 1)
+    mean_sm = (torch.softmax(refs[0].double(), 1) + torch.softmax(refs[1].double(), 1)) / 2
+    assert abs(top1 - (mean_sm.argmax(1) == lab).double().mean().item() * 100) < 1e-9 and top5 >= top1

@@ -317,6 +317,8 @@ def test_hardware_queue_rule_is_decided_from_the_environment():
     assert choose({"LOCAL_WORLD_SIZE": "4", "CUDA_VISIBLE_DEVICES": "0,1,2,3"}, 8)[0] == "8"
     v, why = choose({"GPU_MAX_HW_QUEUES": "4", "LOCAL_WORLD_SIZE": "8"}, 8)
     assert v is None and "set by the caller" in why
+    v, why = choose({"LOCAL_WORLD_SIZE": "2", "HIP_VISIBLE_DEVICES": "5", "UNITE_RANKS_SHARE_GPU": "1"}, 8)      # bench.py's self-start on a one-GPU box
+    assert v is None and "share" in why
     assert choose({"LOCAL_WORLD_SIZE": "junk"}, 2)[0] == "8"
     assert mask_entries({"HIP_VISIBLE_DEVICES": "0, 2,"}) == 2 and mask_entries({}) is None
 
@@ -346,3 +348,34 @@ def test_bench_self_start_decision(monkeypatch):
     cmd = started["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+
+
+def test_optimizer_frozen_names_are_exact_and_an_aborted_bucket_step_ends_the_run():
+    """FusedAdamW host logic without a device (round-3 advisor findings): (1) a parameter frozen after the optimizer was built is matched by its
+    exact name -- freezing `head.weight` must not freeze `head.weight_g`, while set_unused() prefixes still cover everything below them;
+    (2) abort_step() after some ranges of a per-bucket step were already updated leaves parameters one step apart: every further step is refused."""
+    from types import SimpleNamespace
+    from unite_amd.optim_factory import FusedAdamW
+    names = ["head.weight", "head.weight_g", "clip_decoder.0.w", "blocks.0.w"]
+    params = [torch.nn.Parameter(torch.zeros(4)) for _ in names]
+    fake = SimpleNamespace(names=names, params=params, unused_prefixes=(), total=4096, chunk_groups=lambda group_of: dict(group_of))
+    opt = FusedAdamW([{"params": params}], fake, lr=1e-3)
+    params[0].requires_grad_(False)                              # frozen behind create_optimizer (run_stage2.py:711-746)
+    opt.set_unused(("clip_decoder.",))
+    table = opt._build_chunk_table()
+    assert table == {"head.weight": 1, "head.weight_g": 0, "clip_decoder.0.w": 1, "blocks.0.w": 0} and opt._frozen_group == 1
+    params[0].requires_grad_(True)                               # --lp_ft_epochs switches it back on
+    assert opt._effective_unused() != opt._table_unused
+    assert opt._build_chunk_table() == {"head.weight": 0, "head.weight_g": 0, "clip_decoder.0.w": 1, "blocks.0.w": 0}
+    # an aborted step with nothing updated yet is harmless ...
+    opt._step, opt._open = 3, dict(hp=None, done=[])
+    opt.abort_step()
+    assert opt._step == 2 and opt._open is None
+    opt._check_usable()
+    # ... one that had already updated a range is the end of the run
+    opt._step, opt._open = 3, dict(hp=None, done=[(0, 1024)])
+    opt.abort_step()
+    with pytest.raises(RuntimeError, match="aborted after 1"):
+        opt.begin_step()
+    with pytest.raises(RuntimeError, match="restore a checkpoint"):
+        opt.step()

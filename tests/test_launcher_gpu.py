@@ -113,7 +113,11 @@ def test_run_stage3_synthetic(tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     log = [json.loads(l) for l in open(out / "log.txt")]
-    assert len(log) == 1 and log[0]["epoch"] == 0 and log[0]["train_loss"] > 0 and "train_select_ratio" in log[0] and "val_acc1" in log[0]
+    assert len(log) == 2 and log[0]["epoch"] == 0 and log[0]["train_loss"] > 0 and "train_select_ratio" in log[0] and "val_acc1" in log[0]
+    # the run ends with final_test + merge (run_stage3.py:1393-1409): per-view logits in 0.txt, the headline accuracies as the last log line
+    assert set(log[1]) == {"Final top-1", "Final Top-5"} and 0.0 <= log[1]["Final top-1"] <= log[1]["Final Top-5"] <= 100.0
+    views = open(out / "0.txt").read().splitlines()
+    assert len(views) == 1 + 2 * 4 and views[1].startswith("video_0_") and views[1].count(",") == 4       # 2 batches x 4 views, 5 logits each
     assert (out / "checkpoint-latest.pth").exists() and (out / "src_classifier_latest.pth").exists()
     ck = torch.load(out / "checkpoint-latest.pth", map_location="cpu", weights_only=True)["model"]
     from unite_amd import run_stage3

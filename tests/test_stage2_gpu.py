@@ -181,3 +181,49 @@ def test_stage2_parity_at_the_config3_batch():
         gsum += gj
     assert abs(l_all - sum(ls) / len(ls)) <= 1e-4 * max(1.0, abs(l_all))
     assert rel_l2(g_all, gsum / len(ls)) <= 2e-3
+
+
+@pytest.mark.timeout(1200)
+def test_stage2_full_size_vs_oracle():
+    """BASELINE config 3's MODEL at full size -- vit_base_patch16_224(all_frames=16, num_classes=8): 3136 tokens per clip, i.e. the tiled attention
+    kernels (attention_tiled.hip), the 16 f x 196 sinusoid table, fc_norm(mean over 3136 tokens), the 8-class head -- against the fp32 CPU oracle
+    (modeling_finetune.py:356-383 restated; one forward + backward of two clips), at the B = 2 shape whose eight sub-batches
+    test_stage2_parity_at_the_config3_batch averages into the B = 16 step: logits, cross-entropy, the global gradient norm and gradient tensors
+    from the first, a middle and the last layer.  Tolerances: bf16 operands through 12 blocks (logits abs 3e-2 on O(1) values, loss relative
+    2e-3, gradient norm 2e-2, per-tensor gradients relative L2 5e-2)."""
+    import unite_amd
+    cfg = O.VitCfg()                                     # img 224, patch 16, 768 x 12 x 12, 8 classes, 16 frames
+    assert cfg.num_patches == 3136
+    m = unite_amd.create_model("vit_base_patch16_224", pretrained=False, num_classes=8, all_frames=16, tubelet_size=1,
+                               use_mean_pooling=True, drop_path_rate=0.0, init_scale=0.001)
+    sd = fill_state_dict(vit_shapes(cfg), 41)
+    sd["head.weight"] = sd["head.weight"] * 4.0          # spread the logits: a cross-entropy that depends on them
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == vit_shapes(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    B = 2
+    vid = make_videos(B, 16, 224, 224, seed=42)
+    labels = torch.tensor([5, 2])
+    # ---- oracle: fp32 autograd on the CPU
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    keys = ["patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.q_bias", "blocks.5.mlp.fc1.weight", "blocks.11.attn.proj.weight",
+            "blocks.11.mlp.fc2.bias", "fc_norm.weight", "head.weight"]
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_logits = O.vit_classifier_forward(leaf, vid, cfg)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels)
+    ref_loss.backward()
+    ref_gn = O.grad_norm([p.grad for p in leaf.values()]).item()
+    ref_g = {k: leaf[k].grad.clone() for k in keys}
+    ref_logits, ref_loss = ref_logits.detach(), ref_loss.item()
+    del leaf
+    # ---- HIP path
+    logits = m(vid.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(DEV))
+    loss.backward()
+    torch.testing.assert_close(logits.detach().float().cpu(), ref_logits, atol=3e-2, rtol=2e-2)
+    assert abs(loss.item() - ref_loss) <= 2e-3 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    gn = m.runtime().fp.grad.norm().item()
+    assert abs(gn - ref_gn) <= 2e-2 * ref_gn, (gn, ref_gn)
+    got = dict(m.named_parameters())
+    for k in keys:
+        assert rel_l2(got[k].grad.cpu(), ref_g[k]) <= 5e-2, (k, rel_l2(got[k].grad.cpu(), ref_g[k]))

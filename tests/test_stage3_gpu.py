@@ -366,10 +366,13 @@ def test_stage3_step_vs_reference_golden(strategy, golden_dir):
     oracle/make_golden_stage3.py -> tests/golden/stage3_step.npz), all seven selection strategies.  The committee masks are an INPUT
     (the reference's utils.get_greedy_masks output from the fixture: nothing is re-derived from the HIP teacher's attention), the
     zero-shot probabilities come from unite_clip_similarity on the injected image / text features.  Checked: the similarities (1e-5),
-    the classifier logits of the three student passes (absolute 4e-2 on logits of magnitude <= 5: bf16 GEMM operands, measured 0.035), the
-    selection (exact), source / target / total loss (absolute 2.5e-2, i.e. 6e-3 of the total: a cross-entropy over FOUR clips moves by the
-    logit error, it does not average over 60 k tokens as the stage-1 loss does -- north_star's 1e-3 is held by the stage-1 loss and curve
-    tests), the gradient norm (2e-2) and eight gradient tensors (relative L2 5e-2)."""
+    the classifier logits of the three student passes (absolute 4e-2 on logits of magnitude <= 5: bf16 GEMM operands), then -- against the
+    reference's OWN local variables at the end of its step (sel_mask, preds_full_t, msp_t, ce_target: recorded by the generator) -- the
+    per-clip selection mask EXACTLY, the pseudo-label of every clip EXACTLY, the labels the target loss was taken against EXACTLY, the
+    confidences (1.5e-2); the fixture is built so that no decision is within reach of the logit error (make_golden_stage3.py: top-2 logit gaps
+    >= 0.20, confidences >= 0.025 from their thresholds).  Losses: source / target / total each within max(1e-2 of the reference value, 3e-3)
+    -- a cross-entropy over FOUR clips moves with the logit error, it does not average over 60 k tokens as the stage-1 loss does (north_star's
+    1e-3 is held by the stage-1 loss and curve tests); the gradient norm (2e-2) and eight gradient tensors (relative L2 5e-2)."""
     import numpy as np
     import os
     from unite_amd import ops
@@ -403,11 +406,19 @@ def test_stage3_step_vs_reference_golden(strategy, golden_dir):
     ws = s.runtime().ws
     for name, key in (("s3.logits.src", "logits_s"), ("s3.logits.tgt", "logits_full_t"), ("s3.logits.masked", "logits_masked")):
         torch.testing.assert_close(ws.peek(name).cpu(), torch.from_numpy(z[pre + key]), atol=4e-2, rtol=0)
+    # the reference's own per-clip decisions (its local variables when train_one_epoch returned)
+    ref_sel = torch.from_numpy(z[pre + "sel_mask"]).bool()
+    assert torch.equal(sel.cpu().bool(), ref_sel), (sel.cpu().tolist(), ref_sel.tolist())
+    pseudo = ws.peek("s3.pseudo").cpu()
+    assert torch.equal(pseudo, torch.from_numpy(z[pre + "pseudo_labels"])), (pseudo.tolist(), z[pre + "pseudo_labels"].tolist())
+    assert torch.equal(pseudo[ref_sel], torch.from_numpy(z[pre + "ce_target"]))
+    torch.testing.assert_close(ws.peek("s3.msp").cpu(), torch.from_numpy(z[pre + "msp_t"]), atol=1.5e-2, rtol=0)
     assert float(sel.float().mean()) == float(z[pre + "select_ratio"])
-    tot = float(z[pre + "loss"])
-    assert abs(loss_s.item() - float(z[pre + "loss_s"])) <= 2.5e-2
-    assert abs(loss_t.item() - float(z[pre + "loss_t"])) <= 2.5e-2
-    assert abs(loss.item() - tot) <= 2.5e-2
+    for got, key in ((loss_s, "loss_s"), (loss_t, "loss_t"), (loss, "loss")):
+        ref = float(z[pre + key])
+        err = abs(got.item() - ref)
+        print(f"[stage3 golden] {strategy:18s} {key:7s} ref {ref:.6f} err {err:.2e} bound {max(1e-2 * abs(ref), 3e-3):.2e}")
+        assert err <= max(1e-2 * abs(ref), 3e-3), (key, got.item(), ref)
     loss.backward()
     grads = {kk: p.grad for kk, p in s.named_parameters()}
     gn = torch.sqrt(sum((g.float() ** 2).sum() for kk, g in grads.items() if g is not None and not kk.startswith("clip_decoder."))).item()

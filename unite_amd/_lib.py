@@ -63,6 +63,8 @@ SIGNATURES = {
     "unite_gemm_bf16_grouped": (c_i, [C.POINTER(GemmArgs), c_i, c_p]),
     "unite_prof_enable": (c_i, [c_i, c_i]),
     "unite_prof_summary": (c_i, [C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "unite_clock_probe": (c_i, [c_p, c_i, c_i, c_p]),
+    "unite_clock_stamp": (c_i, [c_p, c_p]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_fwd_bf16in": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),

@@ -1273,6 +1273,9 @@ extern "C" int unite_gemm_bf16_grouped(const unite_gemm_args* args, int32_t coun
         const int rc = check_problem(g, ab, bb);
         if (rc != UNITE_OK) return rc;
         if (g.trans_a != args[0].trans_a || g.trans_b != args[0].trans_b) return UNITE_EINVAL;
+        // the grouped launch runs the plain kernel form: the fused bias sums (row sums of op(A), column sums of the output) are products of the
+        // single-problem launch only -- refuse them instead of returning UNITE_OK with the sums unwritten
+        if (g.rowsum_a_out || g.colsum_out) return UNITE_EINVAL;
         if (i == 0) { p.a = g; p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb; }
         else { p.more[i - 1] = g; p.more_a_bytes[i - 1] = (uint32_t)ab; p.more_b_bytes[i - 1] = (uint32_t)bb; }
         tiles += ((g.M + 127) / 128) * ((g.N + 127) / 128);

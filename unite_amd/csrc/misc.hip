@@ -978,3 +978,44 @@ extern "C" int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void*
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }
+
+
+// ---- diagnostic: shader clock under load (include/unite_hip.h: unite_clock_probe) ---------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t* __restrict__ out, int samples, uint64_t interval_ticks) {
+    if (threadIdx.x != 0) return;
+    uint64_t next = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < samples; ++i) {
+        // bounded wait for the next sample time: the reference counter always advances, so every iteration ends
+        while ((int64_t)(__builtin_amdgcn_s_memrealtime() - next) < 0) __builtin_amdgcn_s_sleep(32);
+        const uint64_t c = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+        out[2 * i] = c;
+        out[2 * i + 1] = r;
+        next += interval_ticks;
+    }
+}
+// one {shader clock, reference clock} pair per XCD, taken by whichever workgroups land there (the counters are per XCD: only pairs of the
+// SAME XCD may be subtracted); an ordinary short kernel in the caller's stream, unlike the resident probe wave above
+__global__ __launch_bounds__(64) void clock_stamp_kernel(uint64_t* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    out[2 * xcc] = __builtin_amdgcn_s_memtime();
+    out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+
+extern "C" int unite_clock_stamp(uint64_t* out, void* stream) {
+    if (!out) return UNITE_EINVAL;
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, out);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_clock_probe(uint64_t* samples_out, int32_t samples, int32_t interval_us, void* stream) {
+    if (!samples_out || samples <= 0 || samples > 65536 || interval_us < 1 || interval_us > 100000) return UNITE_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, samples_out, samples, (uint64_t)interval_us * 100u);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}

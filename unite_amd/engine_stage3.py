@@ -326,6 +326,34 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, data_loader_t
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 
+class _EncoderThenClassifier:
+    """what stage 3 evaluates: the student encoder on ALL tokens (an all-visible mask, run_stage3.py:744-749 / :951-957), mean over the tokens
+    (``pool_outputs`` without a CLS token), the frozen source classifier -> (B, nb_classes) f32 logits; no activations are kept"""
+
+    def __init__(self, encoder, src_classifier, args):
+        if getattr(args, "use_cls_token", False):
+            raise NotImplementedError("use_cls_token is not built")
+        self.encoder, self.src_classifier = encoder, src_classifier
+        self.rt = getattr(encoder, "module", encoder).runtime()
+        self.W = src_classifier.weight.detach().float().contiguous()
+        self.b = src_classifier.bias.detach().float().contiguous()
+
+    def eval(self):
+        self.encoder.eval()
+        self.src_classifier.eval()
+        return self
+
+    def __call__(self, videos):
+        rt = self.rt
+        B, T = videos.shape[0], videos.shape[2]
+        n = T * rt.frame_tokens
+        xv = rt.encode(videos, None, n, "s3val", False, save=False)          # encoder.norm(x) for every token
+        pooled = torch.empty(B, rt.D, dtype=F32, device=videos.device)
+        ops.token_mean_fwd(xv.view(B, n, rt.D), pooled)
+        logits = torch.empty(B, self.W.shape[0], dtype=F32, device=videos.device)
+        return ops.linear_f32_fwd(pooled, self.W, self.b, logits)
+
+
 @torch.no_grad()
 def validation_one_epoch(data_loader, encoder, src_classifier, device, fp32=False, args=None, use_wandb=False, save_preds_path=None):
     """run_stage3.py:714-787: the student encoder on ALL tokens, mean-pooled, through the source classifier; loss / top-1 / top-5."""
@@ -333,25 +361,14 @@ def validation_one_epoch(data_loader, encoder, src_classifier, device, fp32=Fals
     criterion = torch.nn.CrossEntropyLoss()
     metric_logger = utils.MetricLogger(delimiter="  ")
     header = 'Val:'
-    encoder.eval()
-    src_classifier.eval()
-    student = getattr(encoder, "module", encoder)
-    if getattr(args, "use_cls_token", False):
-        raise NotImplementedError("use_cls_token is not built")
-    rt = student.runtime()
-    W, b = src_classifier.weight.detach().float().contiguous(), src_classifier.bias.detach().float().contiguous()
+    net = _EncoderThenClassifier(encoder, src_classifier, args).eval()
     for batch in metric_logger.log_every(data_loader, 10, 1, 0, len(data_loader), header):
         videos = batch[0]
         target = batch[2] if getattr(args, "return_aug_for_val", False) else batch[1]
         videos = videos.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
-        B, T = videos.shape[0], videos.shape[2]
-        n = T * rt.frame_tokens
-        xv = rt.encode(videos, None, n, "s3val", False, save=False)          # encoder.norm(x) for every token, no activations kept
-        pooled = torch.empty(B, rt.D, dtype=F32, device=videos.device)
-        ops.token_mean_fwd(xv.view(B, n, rt.D), pooled)
-        class_logits = torch.empty(B, W.shape[0], dtype=F32, device=videos.device)
-        ops.linear_f32_fwd(pooled, W, b, class_logits)
+        B = videos.shape[0]
+        class_logits = net(videos)
         loss = criterion(class_logits, target)
         acc1, acc5 = accuracy(class_logits, target, topk=(1, 5))
         metric_logger.update(loss=loss.item())
@@ -361,3 +378,24 @@ def validation_one_epoch(data_loader, encoder, src_classifier, device, fp32=Fals
     print('* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}'
           .format(top1=metric_logger.acc1, top5=metric_logger.acc5, losses=metric_logger.loss))
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def final_test(data_loader, model, src_classifier, device, file, args):
+    """run_stage3.py:927-989: every (video, temporal chunk, spatial crop) view of the test set through encoder -> pool_outputs -> src_classifier;
+    the views' logits go to ``file`` in the line format ``engine_for_finetuning.merge`` parses (first line: the LAST batch's acc1, acc5, as the
+    reference writes it), ECE over this rank's soft-max outputs, loss / top-1 / top-5 meters synchronised over the ranks."""
+    from .engine_for_finetuning import _EvalPass, view_line
+    lines = []
+
+    def keep_views(batch, logits, target):
+        ids, chunk_nb, split_nb = batch[2], batch[3], batch[4]
+        rows, tgt = logits.cpu(), target.cpu()
+        lines.extend(view_line(ids[i], rows[i], tgt[i], chunk_nb[i], split_nb[i]) for i in range(rows.size(0)))
+
+    ev = _EvalPass(_EncoderThenClassifier(model, src_classifier, args), device, 'Test:').run(data_loader, per_batch=keep_views)
+    ev.calibration(gather=False)
+    with open(file, 'w') as f:
+        f.write("{}, {}\n".format(*ev.last_acc))
+        f.writelines(lines)
+    return ev.summary()

@@ -9,6 +9,8 @@ one GPU with eight queues each oversubscribe the hardware queues, which the driv
 
 The rule (`choose`):
   * GPU_MAX_HW_QUEUES already set                      -> left alone
+  * UNITE_RANKS_SHARE_GPU=1 (set by a launcher that KNOWS it starts more ranks than there are GPUs: bench.py's self-start on a one-GPU
+    box, the two-rank rehearsals of the tests)         -> the default pool stays
   * the visible-device mask names ONE device           -> this rank owns it (the one-GPU-per-rank launchers: HIP_VISIBLE_DEVICES=<local rank>)  -> 8
   * ranks on this node (LOCAL_WORLD_SIZE) <= GPUs seen -> every rank has its own                                                           -> 8
     (GPUs seen: the mask's entries, else the GPU nodes under /sys/class/kfd; unknown counts as enough)
@@ -55,12 +57,15 @@ def choose(env: Mapping[str, str], gpus_on_node: Optional[int]) -> Tuple[Optiona
     """(value to set or None, reason) -- pure: `env` is the process environment, `gpus_on_node` the KFD count (None: unknown)"""
     if "GPU_MAX_HW_QUEUES" in env:
         return None, f"GPU_MAX_HW_QUEUES={env['GPU_MAX_HW_QUEUES']} set by the caller"
+    if env.get("UNITE_RANKS_SHARE_GPU", "0") == "1":
+        return None, "the launcher says ranks share a GPU (UNITE_RANKS_SHARE_GPU=1): HIP's default queue pool stays"
     try:
         ranks = max(1, int(env.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
         ranks = 1
     masked = mask_entries(env)
-    if masked == 1:
+    if masked == 1:      # one rank per process mask (SLURM --gpus-per-task=1, HIP_VISIBLE_DEVICES=$LOCAL_RANK); an inherited one-GPU mask with several
+        # ranks looks the same from inside a rank -- the launcher that creates that situation must say so (UNITE_RANKS_SHARE_GPU above)
         return "8", "the visible-device mask names one device: this rank owns it"
     seen = masked if masked is not None else gpus_on_node
     if seen is None or seen == 0:

@@ -101,12 +101,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._chunk_group = self._build_chunk_table()
 
     def _effective_unused(self):
-        """names (prefixes) without a gradient this step: what the engine declared (set_unused) + what the model's runtime reports (layers its
-        last forward did not execute, e.g. blocks above the highest tap under clip_only) + parameters whose requires_grad was switched
-        off AFTER the optimizer was built (run_stage2.py:711-746 freezes layers behind create_optimizer: autograd then leaves their
-        p.grad at None and torch.optim.AdamW skips them -- no moment update, no weight decay; --lp_ft_epochs switches them back on)"""
-        frozen = tuple(n for n, p in zip(self._flat.names, self._flat.params) if not p.requires_grad) if self._flat is not None else ()
-        return tuple(self._unused) + tuple(getattr(self._flat, "unused_prefixes", ()) or ()) + frozen
+        """parameters without a gradient this step, as (name PREFIXES, exact NAMES): prefixes are what the engine declared (set_unused) and what the
+        model's runtime reports (layers its last forward did not execute, e.g. blocks above the highest tap under clip_only); exact names are the
+        parameters whose requires_grad was switched off AFTER the optimizer was built (run_stage2.py:711-746 freezes layers behind
+        create_optimizer: autograd then leaves their p.grad at None and torch.optim.AdamW skips them -- no moment update, no weight decay;
+        --lp_ft_epochs switches them back on).  Frozen names are matched exactly, never as prefixes: freezing `head.weight` must not freeze a
+        `head.weight_g` beside it."""
+        frozen = frozenset(n for n, p in zip(self._flat.names, self._flat.params) if not p.requires_grad) if self._flat is not None else frozenset()
+        return tuple(self._unused) + tuple(getattr(self._flat, "unused_prefixes", ()) or ()), frozen
 
     def no_grad_chunks(self):
         """(chunk -> group table, id of the group without gradients) for the masked gradient norm; (None, -1) if every parameter has one"""
@@ -128,7 +130,8 @@ class FusedAdamW(torch.optim.Optimizer):
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 group_of[name_of[id(p)]] = gi
-        missing = [n for n in fp.names if n not in group_of or n.startswith(self._table_unused or ("\0",))]
+        prefixes, frozen = self._table_unused
+        missing = [n for n in fp.names if n not in group_of or n in frozen or n.startswith(prefixes or ("\0",))]
         if missing:
             # parameters outside the optimizer (frozen / filtered / without gradient): a group the kernel skips (lr < 0)
             if len(self.param_groups) >= 64:
@@ -179,6 +182,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
+        self._check_usable()
         if not self._ready:
             self._prepare()
         if getattr(self, "_open", None) is not None:      # begin_step() ... step_range() ...: update what is left, close the step
@@ -205,6 +209,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def begin_step(self):
         if self._step_params is not None:
             raise RuntimeError("per-bucket AdamW and the captured (device-parameter) step are mutually exclusive")
+        self._check_usable()
         if not self._ready:
             self._prepare()
         self._refresh_unused()
@@ -227,11 +232,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self._open["done"].append((lo, hi))
 
     def abort_step(self):
-        """drop a step opened by begin_step() whose backward did not complete: ranges already updated stay updated (their gradients were
-        final), the step count goes back so that the next begin_step() does not skip a bias-correction step"""
+        """drop a step opened by begin_step() whose backward did not complete.  If no range had been updated yet the optimizer is as it was
+        (the step count goes back).  If some ranges HAD been updated, parameters of different layers are now one optimisation step apart -- and
+        differ from the other ranks' -- and nothing here can undo that: the optimizer refuses every further step (RuntimeError from begin_step /
+        step), so a caller that swallows the backward's exception and carries on cannot train an inconsistent model; resume from a checkpoint."""
         if getattr(self, "_open", None) is not None:
+            done = len(self._open["done"])
             self._open = None
             self._step -= 1
+            if done:
+                self._broken = f"a per-bucket AdamW step was aborted after {done} of its ranges had been updated"
+
+    def _check_usable(self):
+        if getattr(self, "_broken", None):
+            raise RuntimeError(self._broken + ": the parameters are inconsistent (and differ between ranks); restore a checkpoint")
 
     def _finish_open_step(self, grad_scale=None):
         done = sorted(self._open["done"])

@@ -183,6 +183,10 @@ def main(args, ds_init=None):
     final = {}
     if args.output_dir:
         if args.test_best:
+            # every rank reads the checkpoint rank 0 wrote in the last end_of_epoch: wait until it is complete (the reference sleeps 10 s here,
+            # run_stage2.py:825-829; the file itself appears atomically, utils.save_on_master)
+            if utils.is_dist_avail_and_initialized():
+                torch.distributed.barrier()
             utils.auto_load_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)
         final = test_and_merge()
         if final and utils.is_main_process():

@@ -6,7 +6,8 @@ CLIP mask teacher, the source classifier -- nn.Linear or a two-layer MLP on the 
 ``head.*`` rows of --student_init (:1203-1211) -- which is kept OUTSIDE the optimizer and outside DistributedDataParallel exactly as the
 reference leaves it (:1264 builds the optimizer from the student only: SURVEY Appendix A-8), linear lr scaling by the global batch x 2
 domains, layer-decay assigner (inert on 'encoder.*' names, A-7), cosine schedules, optional initial validation, per epoch
-``train_one_epoch`` + validation every ``val_interval`` epochs, checkpoints + ``src_classifier_latest.pth`` (:1371-1372), log.txt.
+``train_one_epoch`` + validation every ``val_interval`` epochs, checkpoints + ``src_classifier_latest.pth`` (:1371-1372), log.txt, and at the
+end ``final_test`` over the test views + ``merge`` -> 'Final top-1 / Final Top-5' in log.txt (:1393-1409).
 Not here: the dataset stack (--synthetic), OpenAI CLIP's text tower -- the zero-shot probabilities of the clip_* selection strategies come
 from the frozen CLIP IMAGE tower of this build (random-init offline, or --clip_teacher_weights) against class text features loaded from
 ``--clip_text_features`` (a .pt / .npy of shape (nb_classes, C)) or, under --synthetic, seeded random ones."""
@@ -23,7 +24,8 @@ import torch.nn as nn
 
 from . import cli, clip, launch, utils
 from .checkpoint import load_student_from_ckpt_stage3, read_checkpoint
-from .engine_stage3 import train_one_epoch, validation_one_epoch
+from .engine_for_finetuning import merge
+from .engine_stage3 import final_test, train_one_epoch, validation_one_epoch
 from .optim_factory import create_optimizer
 from .registry import create_model
 from .utils import NativeScalerWithGradNormCount as NativeScaler
@@ -101,6 +103,11 @@ def main(args):
     data_loader_train = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed, source_batch)
     data_loader_train_target = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed + 1, target_batch)
     data_loader_val = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 2, val_batch)
+
+    def test_batch(g, B):        # (videos, label, id, chunk, split) -- the test-mode dataset's tuple, final_test reads all five (:939-944)
+        ids = [f"video_{utils.get_rank()}_{int(torch.randint(0, 1 << 30, (1,), generator=g, device=device))}" for _ in range(B)]
+        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), ids, [0] * B, [0] * B
+    data_loader_test = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 3, test_batch)
     log_writer = launch.make_log_writer(args)
     num_training_steps_per_epoch = len(data_loader_train)
 
@@ -180,9 +187,25 @@ def main(args):
         if args.output_dir and args.checkpoints_enabled and utils.is_main_process() and src_classifier is not None:
             utils.save_on_master(src_classifier.state_dict(), Path(args.output_dir) / "src_classifier_latest.pth")
     print('Training time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
+
+    # ---- testing (run_stage3.py:1393-1409): per-view logits of every rank -> '<rank>.txt', merged on rank 0 into the run's headline accuracy
+    final = {}
+    if args.output_dir and src_classifier is not None:
+        global_rank, num_tasks = utils.get_rank(), utils.get_world_size()
+        final_test(data_loader_test, model, src_classifier, device, os.path.join(args.output_dir, str(global_rank) + '.txt'), args)
+        if utils.is_dist_avail_and_initialized():
+            torch.distributed.barrier()
+        if global_rank == 0:
+            print("Start merging results...")
+            top1, top5 = merge(args.output_dir, num_tasks)
+            print(f"Accuracy of the network on the test videos: Top-1: {top1:.2f}%, Top-5: {top5:.2f}%")
+            final = {'Final top-1': top1, 'Final Top-5': top5}
+            import json
+            with open(os.path.join(args.output_dir, "log.txt"), mode="a", encoding="utf-8") as f:
+                f.write(json.dumps(final) + "\n")
     if utils.is_dist_avail_and_initialized():
         torch.distributed.destroy_process_group()
-    return {**train_stats, **{f'val_{k}': v for k, v in val_stats.items()}}
+    return {**train_stats, **{f'val_{k}': v for k, v in val_stats.items()}, **final}
 
 
 if __name__ == '__main__':

@@ -286,9 +286,22 @@ def is_main_process():
     return get_rank() == 0
 
 
-def save_on_master(*args, **kwargs):
-    if is_main_process():
-        torch.save(*args, **kwargs)
+def save_on_master(obj, path, **kwargs):
+    """rank 0 writes `obj` to `path` -- into a temporary file beside it first, renamed over the target once complete, so that a reader on
+    another rank (or a resumed job) never sees a half-written checkpoint (the reference writes in place and sleeps before reading back,
+    run_stage2.py:825-829)"""
+    if not is_main_process():
+        return
+    if isinstance(path, (str, os.PathLike)):
+        tmp = f"{os.fspath(path)}.tmp{os.getpid()}"
+        try:
+            torch.save(obj, tmp, **kwargs)
+            os.replace(tmp, path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    else:                                           # a file object: the caller owns it
+        torch.save(obj, path, **kwargs)
 
 
 def init_distributed_mode(args):
