@@ -1,5 +1,8 @@
 /* unite_comm.h -- the collective side of the data-parallel hot path (unite_comm_{init,allreduce_bucket,broadcast,destroy})
- * as a C ABI over RCCL, in its own library (unite_amd/lib/libunite_comm.so, the only one that links librccl).
+ * as a C ABI over RCCL, in its own library (unite_amd/lib/libunite_comm.so).  RCCL is BOUND AT RUN TIME (dlopen), never linked: the library
+ * uses the librccl.so the process has already mapped -- in a PyTorch process the wheel's copy, the one torch.distributed's "nccl" backend
+ * runs on -- so that exactly ONE RCCL runtime lives in the process; a host without one mapped gets the copy named by unite_comm_bind() /
+ * UNITE_RCCL_LIB, else the system's (ld.so search path, /opt/rocm/lib).
  *
  * What it replaces in the reference: torch.nn.parallel.DistributedDataParallel's bucketed gradient all-reduce and its initial parameter
  * broadcast (run_stage1.py:809, run_stage2.py DDP wrap, run_stage3.py:942; process-group setup src/utils.py:510-551).  One communicator per
@@ -18,6 +21,11 @@ extern "C" {
 
 #define UNITE_COMM_ID_BYTES 128
 
+/* optional, before any other call: bind RCCL now, preferring a copy already mapped into the process, then `rccl_path` (may be NULL), then
+ * UNITE_RCCL_LIB, then the system's.  Every other entry point binds by itself on first use.  0, or -3 if no usable librccl was found. */
+int unite_comm_bind(const char* rccl_path);
+/* the file the bound RCCL comes from (dladdr of ncclAllReduce), NUL-terminated into out[bytes]; binds if necessary */
+int unite_comm_library(char* out, size_t bytes);
 /* rank 0 creates the rendezvous id (ncclGetUniqueId) and hands it to the other ranks by any host channel (the launcher's store, a file) */
 int unite_comm_unique_id(void* id_out, size_t bytes);
 /* collective over all ranks: joins the communicator for the CURRENT HIP device */

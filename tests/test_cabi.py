@@ -139,3 +139,19 @@ def test_grouped_gemm_refuses_the_fused_bias_sums():
         arr = (_lib.GemmArgs * 2)(problem(), problem(**bad))
         assert lib.unite_gemm_bf16_grouped(arr, 2, None) == -1, bad
     # (a schedule hint that is not 0 / 1 cannot be expressed: plan_flags bit 3 IS the value)
+
+
+def test_one_rccl_per_process():
+    """libunite_comm.so binds RCCL at run time and must end up on the copy PyTorch ships (the one torch.distributed's "nccl" backend runs on):
+    round 3's library LINKED /opt/rocm/lib/librccl.so beside the wheel's, two RCCL runtimes in one process (27.5 vs 20.4 ms per step in the
+    one-rank rehearsal).  Checked without a GPU: the bound file, the dynamic section of the .so, and this process's memory map."""
+    import subprocess
+    import torch
+    from unite_amd import _lib
+    bound = os.path.realpath(_lib.comm_library())
+    wheel = os.path.realpath(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    assert bound == wheel, (bound, wheel)
+    needed = subprocess.run(["readelf", "-d", _lib.COMM_LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed, needed                      # nothing of RCCL is linked
+    mapped = {os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps") if "librccl" in l}
+    assert mapped == {wheel}, mapped

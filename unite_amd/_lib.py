@@ -141,6 +141,8 @@ def load() -> C.CDLL:
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libunite_comm.so")
 COMM_ID_BYTES = 128
 COMM_SIGNATURES = {
+    "unite_comm_bind": (c_i, [C.c_char_p]),
+    "unite_comm_library": (c_i, [C.c_char_p, c_sz]),
     "unite_comm_unique_id": (c_i, [c_p, c_sz]),
     "unite_comm_init": (c_i, [c_i, c_i, c_p, c_sz]),
     "unite_comm_allreduce_bucket": (c_i, [c_p, c_i64, c_i, c_i, c_p]),
@@ -164,8 +166,22 @@ def load_comm() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # ONE RCCL per process: bind the copy PyTorch has mapped (or will map: the wheel's lib/librccl.so) instead of the system's
+    import torch
+    wheel = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rc = lib.unite_comm_bind(wheel.encode() if os.path.exists(wheel) else None)
+    if rc != 0:
+        raise UniteHipError("libunite_comm.so found no usable librccl.so (looked at the process's mapped libraries, "
+                            f"{wheel}, UNITE_RCCL_LIB and the system search path)")
     _comm = lib
     return lib
+
+
+def comm_library() -> str:
+    """the file the bound RCCL comes from (diagnostic: it must be the one torch.distributed's nccl backend uses)"""
+    buf = C.create_string_buffer(1024)
+    check_comm(load_comm().unite_comm_library(buf, 1024), "unite_comm_library")
+    return buf.value.decode()
 
 
 def check_comm(code: int, what: str) -> None:
