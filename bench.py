@@ -460,7 +460,7 @@ def main():
         # HBM bytes per MFMA-kernel launch: NOT measured by this run (PMC counters need rocprofv3: tools/final_prof.sh collects the
         # FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial` and tools/pmc_traffic.py reduces them); quoted with its source, or null
         traffic, traffic_source = None, None
-        for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
+        for name in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tp):
                 tj = json.load(open(tp))

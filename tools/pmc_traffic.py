@@ -3,7 +3,7 @@
 profiles/<name>.json:  python tools/pmc_traffic.py <fetch_csv> <write_csv> <out_json>
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2;
 WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB."""
-import csv, json, subprocess, sys
+import csv, json, os, subprocess, sys
 def agg(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
@@ -15,7 +15,9 @@ w, nw = agg(sys.argv[2], "WRITE_SIZE")
 out = {"launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_per_launch_corrected": f * 1024 * 2 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1),
        "traffic_bytes_per_launch": f * 1024 * 2 / max(nf, 1) + w * 1024 / max(nw, 1),
-       "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "(snapshot without .git: see the commit that added this file)",
+       # the GPU box gets a snapshot without .git: the caller passes the commit in (UNITE_COMMIT=$(git rev-parse --short HEAD) inside the gpurun command)
+       "commit": os.environ.get("UNITE_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+       or "(unknown: UNITE_COMMIT was not set and the snapshot has no .git)",
        "note": "MFMA-kernel launches of bench.py (all GEMM shapes of the stage-1 step + the fused teacher projection/attention kernel); FETCH_SIZE x2 per the gfx950 correction"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)

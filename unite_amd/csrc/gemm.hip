@@ -45,7 +45,7 @@ struct Params {
                                   // LAST sums the slabs in slice order (+ the old output if accumulate) and writes the tile
     uint32_t* counters;           // one arrival counter per output tile (zero outside a launch)
     float* rowsum_slab;           // f32 [splitk][M] per-slice row sums of op(A) (rowsum_a_out with split-K)
-    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores)
+    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores; 3: no LDS staging writes; 4: staging + barriers only)
     float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
     int32_t separate_reduce;      // split-K: the slices only write their slabs (and row-sum slabs); splitk_finish_kernel sums them afterwards
@@ -741,9 +741,12 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
+                    for (int r = 0; r < 4; ++r) {
+                        if (p.debug_skip == 3) asm volatile("" ::"v"(acc[h][i][nh][j][r]));      // timing experiment: no staging writes
+                        else cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
+                    }
         __syncthreads();
+        if (p.debug_skip == 4) { __syncthreads(); continue; }      // timing experiment: the staging writes and the barriers only
 #pragma unroll 2
         for (int e = 0; e < TILE / 32; ++e) {
             const int lr = (tid + e * 4 * HALF) / CPR;
@@ -1462,7 +1465,12 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         static const int gr_env = getenv("UNITE_GEMM_GROUP_ROWS") ? atoi(getenv("UNITE_GEMM_GROUP_ROWS")) : -1;
         const int tile_e = kind == 2 ? 256 : 128;
         const bool deep = g.K >= 4096 && (g.M + tile_e - 1) / tile_e >= 8 && (g.N + tile_e - 1) / tile_e >= 8;
-        p.group_rows = gr_env >= 0 ? gr_env : (deep ? 4 : 0);
+        // round 4: the same walk in groups of eight tile rows for the teacher's SHALLOW, WIDE products (c_fc, qkv: K = 768, 9-12 tile columns, 197 tile
+        // rows).  Timed in short bursts it changes nothing (round 3); in a sustained loop -- where the chip sits at its power limit and time measures
+        // energy -- it is -2 .. -3 % (294 vs 301 us c_fc, 193 vs 199 us qkv: fewer weight-panel re-reads from beyond the L2), and +1 .. +8 % on the
+        // three-column c_proj, which therefore keeps the plain order (profiles/r04_clock_notes.txt)
+        const bool shallow_wide = kind == 2 && g.K <= 1024 && (g.M + tile_e - 1) / tile_e >= 64 && (g.N + tile_e - 1) / tile_e >= 8;
+        p.group_rows = gr_env >= 0 ? gr_env : (deep ? 4 : shallow_wide ? 8 : 0);
     }
     hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
