@@ -255,6 +255,17 @@ size_t unite_crop_resize_workspace(int32_t B, int32_t T, int32_t H, int32_t OH, 
 int unite_crop_resize_u8(const uint8_t* frames, const int32_t* boxes_host, uint8_t* out, int32_t B, int32_t T, int32_t H, int32_t W,
                          int32_t OH, int32_t OW, void* workspace, void* stream);
 
+/* ---- stage-2 / stage-3 input path (src/datasets/kinetics_sparse.py:132-281)
+ * Validation / test views: Resize(short side, 'bilinear') on decoded uint8 frames is cv2.resize(INTER_LINEAR) in the reference
+ * (functional_umt.py:44-66).  frames uint8 [T,H,W,3] -> out uint8 [T,OH,OW,3] by OpenCV's published 8-bit fixed-point algorithm (11-bit
+ * weights, the two-shift vertical pass).  cv2 is not in the build image: checked bit for bit against oracle/cv2_resize.py only. */
+int unite_resize_u8_linear(const uint8_t* frames, uint8_t* out, int32_t T, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
+/* Training clips, everything behind RandAugment in _aug_frame (:232-262): ToTensor, tensor_normalize, random_resized_crop (crop box
+ * (i, j, h, w) drawn on the host, then ATen's bilinear interpolate, align_corners = False, to S x S; video_transforms.py:560-592), horizontal flip.
+ * frames uint8 [T,H,W,3] (after RandAugment) -> out f32 [3,T,S,S]. */
+int unite_train_clip_u8(const uint8_t* frames, float* out, int32_t T, int32_t H, int32_t W, int32_t S, int32_t crop_i, int32_t crop_j,
+                        int32_t crop_h, int32_t crop_w, int32_t flip, const float* mean3, const float* std3, void* stream);
+
 /* Bicubic resize of `planes` f32 images H x W -> OH x OW with the semantics of
  * torch.nn.functional.interpolate(mode='bicubic', align_corners=False) (A = -0.75, clamped taps):
  * the teacher-input resize of run_stage1.py:362-368 / run_stage3.py:438-445 (224 -> 196 for CLIP-L/14). */

@@ -231,3 +231,69 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and 0.0 < rec["final_loss"] < 4.0 and "share" in rec["hw_queues"]
+
+
+def _write_cls_videos(root, n, seed, n_cls=4):
+    """labelled .npy clips of 240 x 320 (landscape) / 320 x 240 (portrait) frames: the short side is NOT the 224 the transforms ask for, so
+    validation / test views go through the device resize"""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    lines = []
+    for i in range(n):
+        F = int(rng.randint(10, 24))
+        hw = (320, 240) if i % 3 == 2 else (240, 320)
+        np.save(root / f"cls{seed}_{i}.npy", rng.randint(0, 256, size=(F, hw[0], hw[1], 3), dtype=np.uint8))
+        lines.append(f"cls{seed}_{i}.npy {i % n_cls}")
+    ann = root / f"cls_list{seed}.txt"
+    ann.write_text("\n".join(lines) + "\n")
+    return ann
+
+
+@pytest.mark.timeout(900)
+def test_run_stage2_on_npy_videos(tmp_path):
+    """``python -m unite_amd.run_stage2`` WITHOUT --synthetic (run_stage2.py:492-563): train / validation / test lists through
+    unite_amd/datasets_cls.py -- RandAugment + every draw in two loader workers, the pixels on the GPU -- one epoch, validation, final_test over
+    2 temporal x 3 spatial views per test video, merge."""
+    tr, va, te = _write_cls_videos(tmp_path, 8, 11), _write_cls_videos(tmp_path, 4, 12), _write_cls_videos(tmp_path, 3, 13)
+    cfg = tmp_path / "stage2.yaml"
+    cfg.write_text(yaml.safe_dump(dict(
+        model="vit_base_patch16_224", nb_classes=4, num_frames=4, num_segments=1, tubelet_size=1, use_mean_pooling=True, init_scale=0.001,
+        drop_path=0.0, opt="adamw", opt_betas=[0.9, 0.999], lr=1e-3, min_lr=1e-6, warmup_epochs=0, epochs=1, batch_size=2, update_freq=1,
+        layer_decay=0.65, lr_schedule="cosine", eval_freq=1, save_ckpt_freq=1, frozen_layers="", test_best=False, weight_decay=0.05, smoothing=0.0,
+        input_size=224, short_side_size=224, data_set="Kinetics_sparse", ann_file_train=str(tr), ann_file_val=str(va), ann_file_test=str(te),
+        prefix=str(tmp_path), split=" ", sampling_rate=0, test_num_segment=2, test_num_crop=3, num_workers=2, aa="rand-m7-n4-mstd0.5-inc1",
+        reprob=0.25, remode="pixel", recount=1, train_interpolation="bicubic", num_sample=1, train_fraction=1.0, dist_eval=True)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, "-m", "unite_amd.run_stage2", "--config", str(cfg), "--output_dir", str(out), "--seed", "6"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Use Dataset: Kinetics_sparse" in r.stdout and "Number of training steps per epoch = 4" in r.stdout
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert log[0]["epoch"] == 0 and log[0]["train_loss"] > 0 and "val_acc1" in log[0] and "Final top-1" in log[1]
+    views = open(out / "0.txt").read().splitlines()
+    assert len(views) == 1 + 3 * 2 * 3 and {v.split(" ")[0] for v in views[1:]} == {f"cls13_{i}" for i in range(3)}
+
+
+@pytest.mark.timeout(900)
+def test_run_stage3_on_npy_videos(tmp_path):
+    """``python -m unite_amd.run_stage3`` WITHOUT --synthetic (run_stage3.py:1042-1145): the source list in train mode, the (shorter, repeated)
+    target list in validation mode with its RandAugment second view, validation, final_test + merge."""
+    src, tgt, va, te = (_write_cls_videos(tmp_path, n, s) for n, s in ((6, 21), (4, 22), (4, 23), (2, 24)))
+    cfg = tmp_path / "stage3.yaml"
+    cfg.write_text(yaml.safe_dump(dict(
+        model="adaptation_umt_base_patch16_224", num_frames=8, tubelet_size=1, clip_decoder_embed_dim=768, clip_output_dim=512,
+        clip_return_layers=[6], clip_teacher="clip_b16", clip_return_attn=True, mask_type="attention", mask_ratio=0.8, masking_type="clip_attention",
+        drop_path=0.0, opt="adamw", opt_betas=[0.9, 0.95], lr=1e-4, warmup_epochs=0, epochs=1, batch_size=2, batch_size_val=4, log_freq=1,
+        use_cls_token=False, save_ckpt_freq=1, nb_classes=4, src_classifier_type="linear", class_loss_src_ratio=1.0, selection_strategy="consORconf",
+        val_interval=1, return_aug_for_val=True, input_size=224, short_side_size=224, data_set="Kinetics_sparse", ann_file_train=str(src),
+        ann_file_train_target=str(tgt), ann_file_val=str(va), ann_file_test=str(te), prefix=str(tmp_path), split=" ", sampling_rate=0,
+        test_num_segment=2, test_num_crop=3, num_workers=2, aa="rand-m7-n4-mstd0.5-inc1", reprob=0.25, remode="pixel", recount=1,
+        train_interpolation="bicubic", num_sample=1, train_fraction=1.0, train_repetitions=0)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, "-m", "unite_amd.run_stage3", "--config", str(cfg), "--output_dir", str(out), "--seed", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Repeating target dataset 2 times" in r.stdout and "Number of training steps per epoch = 3" in r.stdout
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert log[0]["epoch"] == 0 and log[0]["train_loss"] > 0 and "train_select_ratio" in log[0] and "val_acc1" in log[0] and "Final top-1" in log[1]
+    assert len(open(out / "0.txt").read().splitlines()) == 1 + 2 * 2 * 3

@@ -79,6 +79,8 @@ SIGNATURES = {
     "unite_clip_u8_to_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "unite_crop_resize_workspace": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "unite_crop_resize_u8": (c_i, [c_p, C.POINTER(c_i), c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "unite_resize_u8_linear": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "unite_train_clip_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_p]),
     "unite_resize_bicubic": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "unite_im2col_gather": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "unite_gather_rows_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -980,6 +980,81 @@ extern "C" int unite_cast_f32_bf16(const float* src, void* dst, int64_t n, void*
 }
 
 
+// ---- stage-2 / stage-3 input path (src/datasets/kinetics_sparse.py) -----------------------------------------------------------------------
+// (1) validation / test: Resize(short side, 'bilinear') of the decoded uint8 frames = cv2.resize(..., INTER_LINEAR) (functional_umt.py:58-66).
+// OpenCV's 8-bit linear resize in fixed point, as published (imgproc/resize.cpp): per output column fx = (float)((dx + 0.5) * scale_x - 0.5),
+// sx = floor(fx), the fraction in 11 bits (saturate_cast<short>(f * 2048), round half to even), clamped at the borders (fraction 0); rows alike;
+// horizontal pass in int (S[sx] * a0 + S[sx + 1] * a1), vertical pass  (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+// cv2 is not in the build image: this is held bit for bit to oracle/cv2_resize.py (the same published algorithm in numpy), "parity unpinned".
+__device__ __forceinline__ void cv_linear_coef(int d, double scale, int n_src, int& s0, int& s1, int& a0, int& a1, bool horizontal) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (horizontal) {                       // columns: the fraction is dropped at both borders, the second tap is never read past the row
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+        s0 = s;
+        s1 = min(s + 1, n_src - 1);
+    } else {                                // rows: the two row indices are clipped, the weights are not
+        s0 = min(max(s, 0), n_src - 1);
+        s1 = min(max(s + 1, 0), n_src - 1);
+    }
+    a0 = (int)(short)__float2int_rn((1.f - f) * 2048.f);
+    a1 = (int)(short)__float2int_rn(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void resize_u8_linear_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int T, int H, int W, int OH,
+                                                               int OW, double scale_x, double scale_y) {
+    const size_t total = (size_t)T * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int dx = (int)(i % OW), dy = (int)((i / OW) % OH), t = (int)(i / ((size_t)OW * OH));
+        int x0, x1, a0, a1, y0, y1, b0, b1;
+        cv_linear_coef(dx, scale_x, W, x0, x1, a0, a1, true);
+        cv_linear_coef(dy, scale_y, H, y0, y1, b0, b1, false);
+        const uint8_t* r0 = src + ((size_t)t * H + y0) * W * 3;
+        const uint8_t* r1 = src + ((size_t)t * H + y1) * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = (int)r0[x0 * 3 + c] * a0 + (int)r0[x1 * 3 + c] * a1;
+            const int h1 = (int)r1[x0 * 3 + c] * a0 + (int)r1[x1 * 3 + c] * a1;
+            dst[i * 3 + c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+}
+
+// (2) training: everything behind RandAugment in _aug_frame (kinetics_sparse.py:232-262) -- ToTensor (/ 255), tensor_normalize, random_resized_crop
+// (crop box, then torch.nn.functional.interpolate(bilinear, align_corners=False) to S x S, video_transforms.py:560-592), horizontal flip -- in ONE
+// pass over the uint8 frames.  ATen's arithmetic: source index max(scale * (d + 0.5) - 0.5, 0) with scale = in / out in f32, second tap one further
+// unless at the border, out = wy0 (wx0 p00 + wx1 p01) + wy1 (wx0 p10 + wx1 p11) on the NORMALISED pixels (the reference normalises before it
+// crops).  The flip mirrors the output column (it comes after the interpolation in the reference).
+__global__ __launch_bounds__(256) void train_clip_kernel(const uint8_t* __restrict__ frames, float* __restrict__ out, int T, int H, int W, int S,
+                                                         int ci, int cj, int ch, int cw, int flip, float m0, float m1, float m2, float s0, float s1,
+                                                         float s2) {
+    const size_t total = (size_t)T * S * S;
+    const float sh = (float)ch / (float)S, sw = (float)cw / (float)S;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % S), y = (int)((i / S) % S), t = (int)(i / ((size_t)S * S));
+        const int xs = flip ? S - 1 - x : x;
+        const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)xs + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)floorf(fy), ch - 1), x0 = min((int)floorf(fx), cw - 1);
+        const float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+        const int y1 = y0 + (y0 < ch - 1 ? 1 : 0), x1 = x0 + (x0 < cw - 1 ? 1 : 0);
+        const uint8_t* base = frames + (size_t)t * H * W * 3;
+        const uint8_t* p00 = base + ((size_t)(ci + y0) * W + cj + x0) * 3;
+        const uint8_t* p01 = base + ((size_t)(ci + y0) * W + cj + x1) * 3;
+        const uint8_t* p10 = base + ((size_t)(ci + y1) * W + cj + x0) * 3;
+        const uint8_t* p11 = base + ((size_t)(ci + y1) * W + cj + x1) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = ((float)p00[c] / 255.0f - mean[c]) / sd[c], v01 = ((float)p01[c] / 255.0f - mean[c]) / sd[c];
+            const float v10 = ((float)p10[c] / 255.0f - mean[c]) / sd[c], v11 = ((float)p11[c] / 255.0f - mean[c]) / sd[c];
+            const float top = (1.f - lx) * v00 + lx * v01, bot = (1.f - lx) * v10 + lx * v11;
+            out[(((size_t)c * T + t) * S + y) * S + x] = (1.f - ly) * top + ly * bot;
+        }
+    }
+}
+
 // ---- diagnostic: shader clock under load (include/unite_hip.h: unite_clock_probe) ---------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t* __restrict__ out, int samples, uint64_t interval_ticks) {
@@ -1016,6 +1091,30 @@ extern "C" int unite_clock_stamp(uint64_t* out, void* stream) {
 extern "C" int unite_clock_probe(uint64_t* samples_out, int32_t samples, int32_t interval_us, void* stream) {
     if (!samples_out || samples <= 0 || samples > 65536 || interval_us < 1 || interval_us > 100000) return UNITE_EINVAL;
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, samples_out, samples, (uint64_t)interval_us * 100u);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+
+extern "C" int unite_resize_u8_linear(const uint8_t* frames, uint8_t* out, int32_t T, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream) {
+    if (!frames || !out || T <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return UNITE_EINVAL;
+    const size_t total = (size_t)T * OH * OW, blocks = (total + 255) / 256;
+    // OpenCV: inv_scale = dsize / ssize in double, scale = 1 / inv_scale
+    const double scale_x = 1.0 / ((double)OW / (double)W), scale_y = 1.0 / ((double)OH / (double)H);
+    hipLaunchKernelGGL(resize_u8_linear_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, frames, out, T, H, W,
+                       OH, OW, scale_x, scale_y);
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_train_clip_u8(const uint8_t* frames, float* out, int32_t T, int32_t H, int32_t W, int32_t S, int32_t crop_i, int32_t crop_j,
+                                   int32_t crop_h, int32_t crop_w, int32_t flip, const float* mean3, const float* std3, void* stream) {
+    if (!frames || !out || !mean3 || !std3 || T <= 0 || H <= 0 || W <= 0 || S <= 0 || crop_h <= 0 || crop_w <= 0 || crop_i < 0 || crop_j < 0 ||
+        crop_i + crop_h > H || crop_j + crop_w > W)
+        return UNITE_EINVAL;
+    const size_t total = (size_t)T * S * S, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(train_clip_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, frames, out, T, H, W, S,
+                       crop_i, crop_j, crop_h, crop_w, flip ? 1 : 0, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
 }

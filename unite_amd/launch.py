@@ -30,8 +30,52 @@ def start_run(args):
 
 def require_synthetic(args, what):
     if not getattr(args, "synthetic", False):
-        raise NotImplementedError(f"the decord / PIL dataset stack of the reference (src/datasets) is not part of this build: run with "
-                                  f"--synthetic, or hand your own loaders to {what}")
+        raise NotImplementedError(f"no input: run with --synthetic, give annotation lists (ann_file_train, ...: unite_amd/datasets_cls.py), or hand "
+                                  f"your own loaders to {what}")
+
+
+def cls_loaders(args, device, num_tasks, global_rank, batch_sizes, *, with_val=True, dist_eval=True, train_repetitions=1, target_annotation=None):
+    """The stage-2 / stage-3 loaders over real video lists (run_stage2.py:492-563, run_stage3.py:1042-1145): ``build_dataset`` for the train /
+    validation / test modes (+ stage 3's target-domain list in validation mode with its augmented second view), the reference's samplers --
+    its own ``DistributedSampler`` with repetitions for training, torch's un-shuffled one for evaluation -- and ``DeviceLoader``s: workers decode
+    and draw, the GPU does the pixel arithmetic (datasets_cls.py).  ``batch_sizes`` = (train, validation, test).  Returns a dict of loaders."""
+    import numpy as np
+    from . import utils
+    from .data import DistributedSampler
+    from .datasets import DeviceLoader
+    from .datasets_cls import build_dataset
+    kw = dict(persistent_workers=True) if args.num_workers > 0 else {}
+
+    def loader(ds, bs, sampler, drop_last, seeded=False):
+        return DeviceLoader(ds, bs, device, sampler=sampler, num_workers=args.num_workers, drop_last=drop_last,
+                            worker_init_fn=utils.seed_worker if seeded else None, **kw)
+
+    def eval_sampler(ds):
+        if dist_eval:
+            return torch.utils.data.DistributedSampler(ds, num_replicas=num_tasks, rank=global_rank, shuffle=False)
+        return torch.utils.data.SequentialSampler(ds)
+
+    dataset_train, args.nb_classes = build_dataset(is_train=True, test_mode=False, args=args)
+    dataset_val = build_dataset(is_train=False, test_mode=False, args=args)[0] if with_val else None
+    dataset_test = build_dataset(is_train=False, test_mode=True, args=args)[0]
+    out = {}
+    if target_annotation:
+        dataset_target, _ = build_dataset(is_train=False, test_mode=False, args=args, annotation_file=target_annotation)
+        if len(dataset_target) < len(dataset_train):
+            target_rep = int(np.ceil(len(dataset_train) / len(dataset_target)))
+            print("Repeating target dataset %d times" % target_rep)
+        else:
+            target_rep = 1
+            train_repetitions = train_repetitions if train_repetitions > 0 else int(np.ceil(len(dataset_target) / len(dataset_train)))
+            print("Repeating source dataset %d times" % train_repetitions)
+        out["target"] = loader(dataset_target, batch_sizes[0], DistributedSampler(dataset_target, num_replicas=num_tasks, rank=global_rank,
+                                                                                  shuffle=True, repetitions=target_rep), True, seeded=True)
+    sampler_train = DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True, repetitions=max(1, train_repetitions))
+    print("Sampler_train = %s" % str(sampler_train))
+    out["train"] = loader(dataset_train, batch_sizes[0], sampler_train, True, seeded=True)
+    out["val"] = loader(dataset_val, batch_sizes[1], eval_sampler(dataset_val), False) if dataset_val is not None else None
+    out["test"] = loader(dataset_test, batch_sizes[2], eval_sampler(dataset_test), False)
+    return out
 
 
 class SyntheticLoader:

@@ -314,6 +314,30 @@ def clip_u8_to_f32(frames, out, mean, std, flip=None):
     return out
 
 
+def resize_u8_linear(frames, out):
+    """frames uint8 (T,H,W,3) -> out uint8 (T,OH,OW,3): OpenCV's 8-bit INTER_LINEAR resize (the reference's validation / test Resize)"""
+    _req(frames, torch.uint8, "frames")
+    _req(out, torch.uint8, "out")
+    T, H, W, Cc = frames.shape
+    assert Cc == 3 and frames.is_contiguous() and out.is_contiguous() and out.shape[0] == T and out.shape[3] == 3
+    _lib.check(_lib.load().unite_resize_u8_linear(_ptr(frames), _ptr(out), T, H, W, out.shape[1], out.shape[2], _stream()), "unite_resize_u8_linear")
+    return out
+
+
+def train_clip_u8(frames, out, box, flip, mean, std):
+    """frames uint8 (T,H,W,3) -> out f32 (3,T,S,S): / 255, normalise, crop box (i, j, h, w), bilinear resize (ATen, align_corners False), flip"""
+    _req(frames, torch.uint8, "frames")
+    _req(out, F32, "out")
+    T, H, W, Cc = frames.shape
+    S = out.shape[-1]
+    assert Cc == 3 and frames.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (3, T, S, S)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    i, j, h, w = (int(v) for v in box)
+    _lib.check(_lib.load().unite_train_clip_u8(_ptr(frames), _ptr(out), T, H, W, S, i, j, h, w, int(bool(flip)), m3, s3, _stream()),
+               "unite_train_clip_u8")
+    return out
+
+
 def crop_resize_workspace(B: int, T: int, H: int, OH: int, OW: int) -> int:
     return int(_lib.load().unite_crop_resize_workspace(B, T, H, OH, OW))
 

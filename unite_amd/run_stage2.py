@@ -7,7 +7,8 @@ schedule the config names (cosine / constant / step) and the cosine weight-decay
 configuration (:711-746: --train_head_only, --frozen_layers [+ --freeze_patch_embedding], --lp_ft_epochs: blocks 0-8 + patch embedding frozen
 for the first epochs, everything trainable from then on), per epoch ``train_one_epoch`` with ``update_freq`` gradient accumulation and the
 scalar logger, validation every ``eval_freq`` epochs (best checkpoint kept), then ``final_test`` + ``merge``.
-Not here: the dataset stack (--synthetic feeds seeded clips / labels), DeepSpeed, Mixup, ModelEma (off in the shipped config; the engine
+Input: --synthetic feeds seeded clips / labels; with ``ann_file_train / ann_file_val / ann_file_test`` lists the loaders come from
+unite_amd/datasets_cls.py (``VideoClsDataset_sparse``: draws in the workers, pixel arithmetic on the GPU).  Not here: DeepSpeed, Mixup, ModelEma (off in the shipped config; the engine
 refuses them)."""
 from __future__ import annotations
 
@@ -79,21 +80,28 @@ def main(args, ds_init=None):
     if ds_init is not None or getattr(args, "enable_deepspeed", False):
         raise NotImplementedError("DeepSpeed is out of scope (enable_deepspeed: false in the shipped config)")
     device, seed = launch.start_run(args)
-    launch.require_synthetic(args, "unite_amd.engine_for_finetuning.train_one_epoch")
     T, size, nb = args.num_frames * args.num_segments, args.input_size, args.nb_classes
     num_tasks, global_rank = utils.get_world_size(), utils.get_rank()
+    if args.synthetic:
+        def train_batch(g, B):       # (samples, targets, ids, extra) as the training dataset yields them (engine_for_finetuning.py:70)
+            return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), None, None
 
-    def train_batch(g, B):       # (samples, targets, ids, extra) as the training dataset yields them (engine_for_finetuning.py:70)
-        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), None, None
+        def eval_batch(g, B):        # (videos, label, id, chunk, split)
+            ids = [f"video_{global_rank}_{int(torch.randint(0, 1 << 30, (1,), generator=g, device=device))}" for _ in range(B)]
+            return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), ids, [0] * B, [0] * B
 
-    def eval_batch(g, B):        # (videos, label, id, chunk, split)
-        ids = [f"video_{global_rank}_{int(torch.randint(0, 1 << 30, (1,), generator=g, device=device))}" for _ in range(B)]
-        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), ids, [0] * B, [0] * B
-
-    steps_per_rank = args.synthetic_steps * args.update_freq
-    data_loader_train = launch.SyntheticLoader(steps_per_rank, args.batch_size, device, seed, train_batch)
-    data_loader_val = None if args.disable_eval_during_finetuning else launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 1, eval_batch)
-    data_loader_test = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 2, eval_batch)
+        steps_per_rank = args.synthetic_steps * args.update_freq
+        data_loader_train = launch.SyntheticLoader(steps_per_rank, args.batch_size, device, seed, train_batch)
+        data_loader_val = None if args.disable_eval_during_finetuning else launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 1, eval_batch)
+        data_loader_test = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 2, eval_batch)
+    elif getattr(args, "ann_file_train", None):
+        # real video lists (run_stage2.py:492-563): validation batches of 2 B, test batches of 4 B, evaluation spread over the ranks
+        ld = launch.cls_loaders(args, device, num_tasks, global_rank, (args.batch_size, int(2 * args.batch_size), int(4 * args.batch_size)),
+                                with_val=not args.disable_eval_during_finetuning, dist_eval=bool(getattr(args, "dist_eval", True)),
+                                train_repetitions=getattr(args, "train_repetitions", 1))
+        data_loader_train, data_loader_val, data_loader_test = ld["train"], ld["val"], ld["test"]
+    else:
+        launch.require_synthetic(args, "unite_amd.engine_for_finetuning.train_one_epoch")
     log_writer = launch.make_log_writer(args)
 
     model = get_model(args)

@@ -8,7 +8,7 @@ reference leaves it (:1264 builds the optimizer from the student only: SURVEY Ap
 domains, layer-decay assigner (inert on 'encoder.*' names, A-7), cosine schedules, optional initial validation, per epoch
 ``train_one_epoch`` + validation every ``val_interval`` epochs, checkpoints + ``src_classifier_latest.pth`` (:1371-1372), log.txt, and at the
 end ``final_test`` over the test views + ``merge`` -> 'Final top-1 / Final Top-5' in log.txt (:1393-1409).
-Not here: the dataset stack (--synthetic), OpenAI CLIP's text tower -- the zero-shot probabilities of the clip_* selection strategies come
+Input: --synthetic, or ``ann_file_train`` + ``ann_file_train_target`` (+ val / test lists) through unite_amd/datasets_cls.py.  Not here: OpenAI CLIP's text tower -- the zero-shot probabilities of the clip_* selection strategies come
 from the frozen CLIP IMAGE tower of this build (random-init offline, or --clip_teacher_weights) against class text features loaded from
 ``--clip_text_features`` (a .pt / .npy of shape (nb_classes, C)) or, under --synthetic, seeded random ones."""
 from __future__ import annotations
@@ -87,27 +87,34 @@ def zero_shot_probs_fn(args, device, seed):
 
 def main(args):
     device, seed = launch.start_run(args)
-    launch.require_synthetic(args, "unite_amd.engine_stage3.train_one_epoch")
     T, size, nb = args.num_frames, args.input_size, args.nb_classes
+    if args.synthetic:
+        def source_batch(g, B):      # (videos, labels, ...) -- run_stage3.py:399-401
+            return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device)
 
-    def source_batch(g, B):      # (videos, labels, ...) -- run_stage3.py:399-401
-        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device)
+        def target_batch(g, B):      # (videos, augmented videos, labels) with return_aug_for_val (:404-411)
+            v = launch.clips(g, B, T, size, device)
+            return v, v + 0.1 * launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device)
 
-    def target_batch(g, B):      # (videos, augmented videos, labels) with return_aug_for_val (:404-411)
-        v = launch.clips(g, B, T, size, device)
-        return v, v + 0.1 * launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device)
+        def val_batch(g, B):         # validation_one_epoch reads batch[0] and batch[2] (or [1]) (:736-742)
+            return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), launch.labels(g, B, nb, device)
 
-    def val_batch(g, B):         # validation_one_epoch reads batch[0] and batch[2] (or [1]) (:736-742)
-        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), launch.labels(g, B, nb, device)
-
-    data_loader_train = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed, source_batch)
-    data_loader_train_target = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed + 1, target_batch)
-    data_loader_val = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 2, val_batch)
-
-    def test_batch(g, B):        # (videos, label, id, chunk, split) -- the test-mode dataset's tuple, final_test reads all five (:939-944)
-        ids = [f"video_{utils.get_rank()}_{int(torch.randint(0, 1 << 30, (1,), generator=g, device=device))}" for _ in range(B)]
-        return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), ids, [0] * B, [0] * B
-    data_loader_test = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 3, test_batch)
+        def test_batch(g, B):        # (videos, label, id, chunk, split) -- the test-mode dataset's tuple, final_test reads all five (:939-944)
+            ids = [f"video_{utils.get_rank()}_{int(torch.randint(0, 1 << 30, (1,), generator=g, device=device))}" for _ in range(B)]
+            return launch.clips(g, B, T, size, device), launch.labels(g, B, nb, device), ids, [0] * B, [0] * B
+        data_loader_train = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed, source_batch)
+        data_loader_train_target = launch.SyntheticLoader(args.synthetic_steps, args.batch_size, device, seed + 1, target_batch)
+        data_loader_val = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 2, val_batch)
+        data_loader_test = launch.SyntheticLoader(2, 2 * args.batch_size, device, seed + 3, test_batch)
+    elif getattr(args, "ann_file_train", None) and getattr(args, "ann_file_train_target", None):
+        # real video lists (run_stage3.py:1042-1145): the source list in train mode, the target list in VALIDATION mode with its augmented second
+        # view (return_aug_for_val), the shorter of the two repeated; validation / test batches of batch_size_val
+        bv = int(getattr(args, "batch_size_val", None) or 2 * args.batch_size)
+        ld = launch.cls_loaders(args, device, utils.get_world_size(), utils.get_rank(), (args.batch_size, bv, bv), with_val=True, dist_eval=True,
+                                train_repetitions=getattr(args, "train_repetitions", 0), target_annotation=args.ann_file_train_target)
+        data_loader_train, data_loader_train_target, data_loader_val, data_loader_test = ld["train"], ld["target"], ld["val"], ld["test"]
+    else:
+        launch.require_synthetic(args, "unite_amd.engine_stage3.train_one_epoch")
     log_writer = launch.make_log_writer(args)
     num_training_steps_per_epoch = len(data_loader_train)
 
