@@ -17,11 +17,16 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import sys
+import time
 from typing import Dict, Hashable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+_COMM_TIMING = os.environ.get("UNITE_COMM_TIMING", "0") == "1"
+_COMM_TIMES: List[float] = []
 
 
 def native_comm(group=None):
@@ -147,8 +152,15 @@ class GradReducer:
                 self.stream.wait_event(ev)
             if self.comm is not None:
                 from . import _lib
+                t0 = time.perf_counter() if _COMM_TIMING else 0.0
                 _lib.check_comm(self.comm.unite_comm_allreduce_bucket(view.data_ptr(), view.numel(), 0, 1, self.stream.cuda_stream),
                                 "unite_comm_allreduce_bucket")
+                if _COMM_TIMING:                   # diagnostic: how long the host thread (autograd's backward thread) sits inside the RCCL call
+                    _COMM_TIMES.append((time.perf_counter() - t0) * 1e3)
+                    if len(_COMM_TIMES) % 100 == 0:
+                        last = _COMM_TIMES[-100:]
+                        print(f"[unite_amd.ddp] native all-reduce enqueue: mean {sum(last) / 100:.3f} ms, max {max(last):.3f} ms over the last 100 calls",
+                              file=sys.stderr, flush=True)
             else:
                 with torch.cuda.stream(self.stream):
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
