@@ -245,6 +245,13 @@ def main():
 
     import unite_amd
     from unite_amd import _lib, ops
+    if (world > 1 or rehearse) and a.backend == "nccl" and os.environ.get("UNITE_COMM_NATIVE", "0") == "1":
+        # the native communicator is created NOW, before the step's streams exist, as torch's process group creates its own at init_process_group.
+        # (Round 4 traced why the one-rank rehearsal through it takes 27.5 instead of 20.5 ms per step: with it, HIP puts the teacher's stream and
+        # the weight-gradient stream on ONE hardware queue -- 189 kernels per step on queue 8, queues 5 and 6 unused -- whatever GPU_MAX_HW_QUEUES
+        # says; creating the communicator early does not change that assignment.  The native path stays opt-in and is not the measured one.)
+        from unite_amd.ddp import native_comm
+        native_comm()
     from unite_amd.ddp import DistributedDataParallel
     from unite_amd.engine_stage1 import StepState, TeacherAhead, stage1_step, student_phase, teacher_phase
     from unite_amd.optim_factory import create_optimizer

@@ -85,7 +85,10 @@ typedef struct unite_gemm_args {
     int32_t plan_flags;                         /* bit 0: plan_persistent is a per-call hint, bit 1: plan_sharing is, bit 2: bit 3 is the
                                                    main-loop schedule of the tile kernels for THIS launch (0: fragment reads at the head
                                                    of each phase, 1: software-pipelined reads between the MFMAs; default UNITE_GEMM_SCHED,
-                                                   1) -- same products bit for bit, an A/B switch */
+                                                   1) -- same products bit for bit, an A/B switch; bit 4: bit 5 is the 256 x 256 kernel's epilogue form where
+                                                   both apply (bf16 output, no residual / saved pre-activation / column sums / split-K): 0 f32 LDS
+                                                   image in two passes, 1 transposed accumulators + one bf16 image (default UNITE_GEMM_EPI) --
+                                                   same bits out */
     int32_t plan_persistent;                    /* as unite_gemm_set_policy, for THIS launch only */
     float   plan_sharing;                       /* as unite_gemm_set_sharing, for THIS launch only */
     int32_t residual_bf16;                      /* `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream) */

@@ -69,6 +69,52 @@ def test_gemm_256_tile_exact_integers(ops, ta, tb, M, N, K):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(4000, 3960, 200), (1288, 776, 1096), (3848, 3592, 72), (520, 264, 3072)])
+def test_gemm_main_loop_schedules_are_bit_identical(ops, ta, tb, M, N, K):
+    """The tile kernels' two main-loop schedules (plan_flags bits 2 / 3: fragment reads at the head of each phase / software-pipelined between
+    the MFMA pairs) issue the same MFMAs on the same accumulators in the same order: random bf16 operands -- ragged in every dimension, K shorter
+    than the prefetch depth, a K of 17 tiles, both tile sizes -- must give the same bits, with a bias + GELU epilogue as well."""
+    a = bf(rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)).to(DEV)
+    b = bf(rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    for kw in (dict(), dict(bias=bias, act=ops.ACT_GELU)):
+        outs = []
+        for sched in (0, 1):
+            out = torch.full((M, N), float("nan"), dtype=torch.float32 if not kw else torch.bfloat16, device=DEV)
+            with ops.plan(persistent=0, sched=sched):
+                ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[1].float()).any()
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(4000, 3960, 200), (3848, 3592, 776)])
+def test_gemm_epilogue_forms_are_bit_identical(ops, ta, tb, M, N, K):
+    """The 256 x 256 kernel's two epilogue forms for bf16 outputs (plan_flags bits 4 / 5): f32 LDS image in two passes / transposed accumulators
+    + one bf16 image.  Same sums, same rounding points: plain, bias, bias + QuickGELU, bias + GELU and a drop-path row scale must agree bit for
+    bit on random operands, ragged in M and N."""
+    a = bf(rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)).to(DEV)
+    b = bf(rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    scale = (torch.rand(M // 8, generator=torch.Generator().manual_seed(4)) > 0.3).float().div(0.7).to(DEV)
+    cases = (dict(), dict(bias=bias), dict(bias=bias, act=ops.ACT_QUICKGELU), dict(bias=bias, act=ops.ACT_GELU),
+             dict(bias=bias, row_scale=scale, rows_per_scale=8))
+    for kw in cases:
+        outs = []
+        for epi in (0, 1):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            with ops.plan(persistent=0, sched=1, epi=epi):
+                ops.gemm(a, b, out, trans_a=ta, trans_b=tb, **kw)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), sorted(kw)
+        assert not torch.isnan(outs[1].float()).any()
+    # and the last case against fp32 torch (bf16 rounding of the output: 2^-8 relative)
+    ref = ((a.float().t() if ta else a.float()) @ (b.float() if tb else b.float().t()) + bias) * scale.repeat_interleave(8)[:M, None]
+    err = (outs[1].float() - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item(), err
+
+
 @pytest.mark.parametrize("ta,tb", [(True, True), (False, False)])
 def test_gemm_grouped_matches_single_launches(ops, ta, tb):
     """unite_gemm_bf16_grouped: four problems of different shapes (the weight gradients of a block) in one launch are

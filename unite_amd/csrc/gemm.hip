@@ -425,7 +425,12 @@ struct FragReader {
 // flags: the extra accumulator, the one-hot fragment and the values the reduction keeps alive cost the 256^2 kernel 16 registers per lane (232 -> 248) -- with 232 a CU that holds a GEMM workgroup still has 48
 // registers per SIMD lane free, enough for a wave of the streaming kernels (LayerNorm, reductions) of another stream to run beside it; with
 // 248 it has not, and the overlapped step was 0.3-0.4 ms slower although every kernel timed alone was unchanged (round 3).
-template <int HALF, bool TA, bool TB, int WG = 0, int SCHED = 0>
+// EPI 1 (SCHED 1, WG 0 only): the products are computed TRANSPOSED (the B fragment in the MFMA's A slot), so a lane holds four consecutive columns
+// of one output row; bias / activation / row scale are applied in the accumulator registers, the results are packed to bf16 there and staged ONCE
+// through a bf16 image of the whole tile (8-byte writes, 128 KiB) instead of twice through an f32 image of half of it (4-byte writes, 2 x 128 KiB):
+// a quarter of the LDS bytes, a quarter of the write instructions, two barriers instead of four.  For bf16 outputs without residual / saved
+// pre-activation / column sums / split-K (the launcher checks); bit-identical to EPI 0 (same sums, same rounding points).
+template <int HALF, bool TA, bool TB, int WG = 0, int SCHED = 0, int EPI = 0>
 __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 2 * HALF, SLOT = HALF * 128, WN = HALF / 32, MT = HALF / 32;
@@ -615,6 +620,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     rb.init(bcol, lane);
     const uint32_t lds0 = lds_address(smem);
     bf16x8 X[MT][2], Y[2][2], Z[2][2];
+    // EPI 1: C^T tiles -- the B fragment goes into the MFMA's A slot, so lane (G, c) ends up with C[row c][columns 4 G .. 4 G + 3] of each 16 x 16 tile
+    auto mm = [](bf16x8 a, bf16x8 b, f32x4 c) { return EPI == 1 ? mfma16(b, a, c) : mfma16(a, b, c); };
     // one LDS-DMA piece (i = 0, 1) of half-tile `kind` of K-tile u
     auto piece = [&](auto kind_c, int u, int i) {
         constexpr int kind = decltype(kind_c)::value;
@@ -644,8 +651,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         static_for<0, NP>([&](auto pc) {
             constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
             if constexpr (pi == MT) { UNITE_LGKM(4 * RB); UNITE_FENCE(); }      // X[.][1], Y[.][1]: younger are the four Z fragments only
-            acc[0][i][0][0] = mfma16(X[i][ks], Y[0][ks], acc[0][i][0][0]);
-            acc[0][i][0][1] = mfma16(X[i][ks], Y[1][ks], acc[0][i][0][1]);
+            acc[0][i][0][0] = mm(X[i][ks], Y[0][ks], acc[0][i][0][0]);
+            acc[0][i][0][1] = mm(X[i][ks], Y[1][ks], acc[0][i][0][1]);
             UNITE_FENCE();
             if constexpr (pi == 0) {
                 Z[0][0] = rb.template read<0, 0, OB1>(cur);
@@ -666,8 +673,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         static_for<0, NP>([&](auto pc) {
             constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
             if constexpr (pi == MT) { UNITE_LGKM(MT * RA); UNITE_FENCE(); }     // Z[.][1]: younger are the MT fragments read behind pairs 0 .. MT-1
-            acc[0][i][1][0] = mfma16(X[i][ks], Z[0][ks], acc[0][i][1][0]);
-            acc[0][i][1][1] = mfma16(X[i][ks], Z[1][ks], acc[0][i][1][1]);
+            acc[0][i][1][0] = mm(X[i][ks], Z[0][ks], acc[0][i][1][0]);
+            acc[0][i][1][1] = mm(X[i][ks], Z[1][ks], acc[0][i][1][1]);
             UNITE_FENCE();
             X[i][ks] = ra.template read<i, ks, OA1>(cur);
             if constexpr (pi == D0) piece(std::integral_constant<int, 0>{}, t + 2, 0);
@@ -680,8 +687,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         static_for<0, NP>([&](auto pc) {
             constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
             if constexpr (pi == MT) { UNITE_LGKM(0); UNITE_FENCE(); }
-            acc[1][i][1][0] = mfma16(X[i][ks], Z[0][ks], acc[1][i][1][0]);
-            acc[1][i][1][1] = mfma16(X[i][ks], Z[1][ks], acc[1][i][1][1]);
+            acc[1][i][1][0] = mm(X[i][ks], Z[0][ks], acc[1][i][1][0]);
+            acc[1][i][1][1] = mm(X[i][ks], Z[1][ks], acc[1][i][1][1]);
             UNITE_FENCE();
             if constexpr (pi == D0) piece(std::integral_constant<int, 1>{}, t + 2, 0);
             if constexpr (pi == D1) piece(std::integral_constant<int, 1>{}, t + 2, 1);
@@ -693,8 +700,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         __builtin_amdgcn_s_barrier();
         static_for<0, NP>([&](auto pc) {
             constexpr int pi = decltype(pc)::value, ks = pi / MT, i = pi % MT;
-            acc[1][i][0][0] = mfma16(X[i][ks], Y[0][ks], acc[1][i][0][0]);
-            acc[1][i][0][1] = mfma16(X[i][ks], Y[1][ks], acc[1][i][0][1]);
+            acc[1][i][0][0] = mm(X[i][ks], Y[0][ks], acc[1][i][0][0]);
+            acc[1][i][0][1] = mm(X[i][ks], Y[1][ks], acc[1][i][0][1]);
             UNITE_FENCE();
             X[i][ks] = ra.template read<i, ks, OA0>(nxt);
             if constexpr (i == MT - 1) {
@@ -720,6 +727,65 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[h][i][nh][j]));
+        return;
+    }
+
+    if constexpr (EPI == 1) {
+        // ---- epilogue from transposed accumulators: lane (G, c) of tile (h, i, nh, j) holds row  h HALF + arow + 16 i + c,  columns  nh HALF + bcol +
+        // 16 j + 4 G .. + 3.  Bias, activation and row scale in the registers, bf16 pairs packed, ONE 8-byte LDS write per tile into a bf16 image of the
+        // whole tile (512-byte rows; the 16-byte chunk index is XORed with row & 15: the 16 lanes of a write group are 16 different rows of one column);
+        // then every thread moves sixteen 16-byte chunks, a wave two whole rows per instruction.
+        char* img = smem;
+        const int G = lane >> 4, c16 = lane & 15;
+        f32x4 bb[2][2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gn = n0 + nh * HALF + bcol + j * 16 + 4 * G;
+                bb[nh][j] = (g.bias && gn < gN) ? *(const f32x4*)(g.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = h * HALF + arow + i * 16 + c16;
+                float sc = 1.f;
+                if (g.row_scale) sc = g.row_scale[min(m0 + row, gM - 1) / g.rows_per_scale];
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v = acc[h][i][nh][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = v[e] + bb[nh][j][e];
+                            if (g.act == UNITE_ACT_GELU) x = gelu_erf(x);
+                            else if (g.act == UNITE_ACT_QUICKGELU) x = quick_gelu(x);
+                            if (g.row_scale) x *= sc;
+                            v[e] = x;
+                        }
+                        const int unit = (nh * HALF + bcol + j * 16 + 4 * G) >> 2;            // 8-byte unit (four bf16) inside the 512-byte row
+                        const u32x2 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2*)(img + row * (TILE * 2) + ((((unit >> 1) ^ (row & 15)) << 4) | ((unit & 1) << 3))) = w;
+                    }
+            }
+        __syncthreads();
+        if (p.debug_skip == 4) return;
+        constexpr int CH = TILE / 8;                         // 16-byte chunks per row
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll 4
+        for (int e = 0; e < TILE * CH / (4 * HALF); ++e) {
+            const int idx = tid + e * 4 * HALF, row = idx / CH, ch = idx % CH;
+            const u32x4 o = *(const u32x4*)(img + row * (TILE * 2) + ((ch ^ (row & 15)) << 4));
+            const int gm = m0 + row, gn = n0 + ch * 8;
+            if (gm < gM && gn < gN) {
+                if (p.debug_skip == 2) asm volatile("" ::"v"(o));
+                else if (p.nt_store == 2) __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
+                else if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
+                else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+            }
+        }
         return;
     }
 
@@ -1122,10 +1188,10 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
 }
 
 // ---- launch of the deep tile kernels: HALF x weight-gradient form x layouts x schedule -> one instantiation
-template <int HALF, bool TA, bool TB, int WG, int SCHED>
+template <int HALF, bool TA, bool TB, int WG, int SCHED, int EPI = 0>
 int launch_deep_one(int nb, hipStream_t s, const Params& p) {
     constexpr int lds = 8 * HALF * 128;
-    auto* k = gemm_deep_kernel<HALF, TA, TB, WG, SCHED>;
+    auto* k = gemm_deep_kernel<HALF, TA, TB, WG, SCHED, EPI>;
     if (lds > 64 * 1024) {      // 128 KiB of dynamic LDS needs the opt-in, once per instantiation
         static bool ok = false;
         if (!ok) {
@@ -1144,11 +1210,23 @@ int launch_deep_layout(bool ta, bool tb, int nb, hipStream_t s, const Params& p)
     if (ta && !tb) return launch_deep_one<HALF, true, false, WG, SCHED>(nb, s, p);
     return launch_deep_one<HALF, true, true, WG, SCHED>(nb, s, p);
 }
+// the 256^2 kernel with the transposed-accumulator bf16 epilogue (EPI 1): schedule 1, plain form
+inline int launch_deep_epi1(bool ta, bool tb, int nb, hipStream_t s, const Params& p) {
+    if (!ta && !tb) return launch_deep_one<128, false, false, 0, 1, 1>(nb, s, p);
+    if (!ta && tb) return launch_deep_one<128, false, true, 0, 1, 1>(nb, s, p);
+    if (ta && !tb) return launch_deep_one<128, true, false, 0, 1, 1>(nb, s, p);
+    return launch_deep_one<128, true, true, 0, 1, 1>(nb, s, p);
+}
 template <int HALF>
 int launch_deep(int wgf, bool ta, bool tb, int sched, int nb, hipStream_t s, const Params& p) {
     if (wgf == 2) return launch_deep_one<HALF, true, true, 2, 0>(nb, s, p);      // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
     if (wgf == 1) return sched ? launch_deep_layout<HALF, 1, 1>(ta, tb, nb, s, p) : launch_deep_layout<HALF, 1, 0>(ta, tb, nb, s, p);
     return sched ? launch_deep_layout<HALF, 0, 1>(ta, tb, nb, s, p) : launch_deep_layout<HALF, 0, 0>(ta, tb, nb, s, p);
+}
+// UNITE_GEMM_EPI = 0 | 1: process default of the 256^2 kernel's epilogue form for the outputs EPI 1 can take (per call: plan_flags bits 4, 5)
+inline int g_epi_env() {
+    static const int v = getenv("UNITE_GEMM_EPI") ? atoi(getenv("UNITE_GEMM_EPI")) : 0;
+    return v != 0;
 }
 // UNITE_GEMM_SCHED = 0 | 1: process default of the main-loop schedule (per call: plan_flags bits 2, 3)
 inline int g_sched_env() {
@@ -1492,7 +1570,13 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
     } else if (kind == 2 || kind == 1) {
         // kernel form x operand layouts x main-loop schedule (0: fragment reads at the head of each phase, 1: software-pipelined, see gemm_deep_kernel)
         const int sched = (wgf == 2) ? 0 : (g.plan_flags & 4) ? ((g.plan_flags >> 3) & 1) : g_sched_env();
-        const int rc = kind == 2 ? launch_deep<128>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p)
+        // epilogue form 1 (transposed accumulators, bf16 image): 256^2 tiles, schedule 1, a bf16 output that needs nothing read or written beside it
+        const bool epi1_ok = kind == 2 && sched == 1 && wgf == 0 && p.splitk == 1 && !g.out_f32 && !g.residual && !g.aux_out && !g.out_bf16_copy &&
+                             !want_colsum && (g.act == UNITE_ACT_NONE || g.act == UNITE_ACT_GELU || g.act == UNITE_ACT_QUICKGELU) && p.ngroups == 1 &&
+                             (!g.bias || (((uintptr_t)g.bias) & 15) == 0);
+        const int epi = epi1_ok ? ((g.plan_flags & 16) ? ((g.plan_flags >> 5) & 1) : g_epi_env()) : 0;
+        const int rc = epi ? launch_deep_epi1(g.trans_a != 0, g.trans_b != 0, nb, s, p)
+                     : kind == 2 ? launch_deep<128>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p)
                                  : launch_deep<64>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p);
         if (rc != UNITE_OK) return rc;
     } else if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), dim3(nb), dim3(256), LDS_BYTES, s, p);

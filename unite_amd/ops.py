@@ -60,28 +60,32 @@ class _PlanHints(threading.local):
     persistent: Optional[int] = None
     sharing: Optional[float] = None
     sched: Optional[int] = None
+    epi: Optional[int] = None
 
 
 _hints = _PlanHints()
 
 
 @contextlib.contextmanager
-def plan(persistent: Optional[int] = None, sharing: Optional[float] = None, sched: Optional[int] = None):
+def plan(persistent: Optional[int] = None, sharing: Optional[float] = None, sched: Optional[int] = None, epi: Optional[int] = None):
     """GEMM launches enqueued inside the block carry these hints (None: leave as is): ``persistent`` as unite_gemm_set_policy
     (0 never / 1 measured shapes / 2 whenever supported), ``sharing`` as unite_gemm_set_sharing (0 .. 1: how much the launch's CU time
     counts against its latency -- the launches share the GPU with another stream), ``sched`` the tile kernels' main-loop schedule
-    (plan_flags bits 2 / 3: 0 reads at the head of each phase, 1 software-pipelined; an A/B switch, the products are bit-identical)."""
-    before = (_hints.persistent, _hints.sharing, _hints.sched)
+    (plan_flags bits 2 / 3: 0 reads at the head of each phase, 1 software-pipelined; an A/B switch, the products are bit-identical), ``epi`` the
+    256 x 256 kernel's epilogue form where both apply (bits 4 / 5: 0 f32 image in two passes, 1 transposed accumulators + bf16 image; same bits out)."""
+    before = (_hints.persistent, _hints.sharing, _hints.sched, _hints.epi)
     if persistent is not None:
         _hints.persistent = int(persistent)
     if sharing is not None:
         _hints.sharing = float(sharing)
     if sched is not None:
         _hints.sched = int(sched)
+    if epi is not None:
+        _hints.epi = int(epi)
     try:
         yield
     finally:
-        _hints.persistent, _hints.sharing, _hints.sched = before
+        _hints.persistent, _hints.sharing, _hints.sched, _hints.epi = before
 
 
 def keep_plan(ctx) -> None:
@@ -198,6 +202,8 @@ def _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scal
         g.plan_sharing = _hints.sharing
     if _hints.sched is not None:
         g.plan_flags |= 4 | (8 if _hints.sched else 0)
+    if _hints.epi is not None:
+        g.plan_flags |= 16 | (32 if _hints.epi else 0)
     return g
 
 

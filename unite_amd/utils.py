@@ -322,6 +322,10 @@ def init_distributed_mode(args):
     dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size, rank=args.rank)
     if backend == "nccl":
         dist.barrier(device_ids=[args.gpu])
+        if os.environ.get("UNITE_COMM_NATIVE", "0") == "1":
+            # libunite_comm.so's communicator at the point where torch creates its own (bench.py has the note on what this does and does not fix)
+            from .ddp import native_comm
+            native_comm()
     else:
         dist.barrier()
 
