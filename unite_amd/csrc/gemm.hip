@@ -621,7 +621,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const uint32_t lds0 = lds_address(smem);
     bf16x8 X[MT][2], Y[2][2], Z[2][2];
     // EPI 1: C^T tiles -- the B fragment goes into the MFMA's A slot, so lane (G, c) ends up with C[row c][columns 4 G .. 4 G + 3] of each 16 x 16 tile
-    auto mm = [](bf16x8 a, bf16x8 b, f32x4 c) { return EPI >= 1 ? mfma16(b, a, c) : mfma16(a, b, c); };
+    auto mm = [](bf16x8 a, bf16x8 b, f32x4 c) { return EPI == 1 ? mfma16(b, a, c) : mfma16(a, b, c); };
     // one LDS-DMA piece (i = 0, 1) of half-tile `kind` of K-tile u
     auto piece = [&](auto kind_c, int u, int i) {
         constexpr int kind = decltype(kind_c)::value;
@@ -786,73 +786,6 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
             }
         }
-        return;
-    }
-
-    if constexpr (EPI == 2) {
-        // ---- f32 outputs straight from the transposed accumulators, no LDS: lane (G, c) owns row  h HALF + arow + 16 i + c  and four consecutive
-        // f32 columns (16 bytes) of each 16 x 16 tile, the four lane groups of a wave 64 contiguous bytes of the row -- whole 32-byte sectors for the
-        // residual loads and the stores alike (unlike the 128 x 256 kernel's DIRECT form, whose lanes own 64 bytes each and store 16-byte pieces at
-        // a 64-byte stride).  Same order of operations as epilogue_chunk: bias, activation, row scale, residual, old output, store, bf16 copy.
-        const int G = lane >> 4, c16 = lane & 15;
-        f32x4 bb[2][2];
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int gn = n0 + nh * HALF + bcol + j * 16 + 4 * G;
-                bb[nh][j] = (g.bias && gn < gN) ? *(const f32x4*)(g.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int gm = m0 + h * HALF + arow + i * 16 + c16;
-                if (gm >= gM) continue;
-                const float sc = g.row_scale ? g.row_scale[gm / g.rows_per_scale] : 1.f;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int gn = n0 + nh * HALF + bcol + j * 16 + 4 * G;
-                        if (gn >= gN) continue;
-                        f32x4 v = acc[h][i][nh][j];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = v[e] + bb[nh][j][e];
-                            if (g.act == UNITE_ACT_GELU) x = gelu_erf(x);
-                            else if (g.act == UNITE_ACT_QUICKGELU) x = quick_gelu(x);
-                            if (g.row_scale) x *= sc;
-                            v[e] = x;
-                        }
-                        if (g.residual) {
-                            if (g.residual_bf16) {
-                                const u32x2 r = *(const u32x2*)((const uint16_t*)g.residual + (size_t)gm * g.ldr + gn);
-                                v[0] += __uint_as_float(r[0] << 16); v[1] += __uint_as_float(r[0] & 0xFFFF0000u);
-                                v[2] += __uint_as_float(r[1] << 16); v[3] += __uint_as_float(r[1] & 0xFFFF0000u);
-                            } else {
-                                const f32x4 r = *(const f32x4*)((const float*)g.residual + (size_t)gm * g.ldr + gn);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += r[e];
-                            }
-                        }
-                        float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
-                        if (g.accumulate) {
-                            const f32x4 o = *(const f32x4*)op;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += o[e];
-                        }
-                        if (p.debug_skip == 2) { asm volatile("" ::"v"(v)); continue; }
-                        if (p.nt_store == 2) {
-                            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                                                   ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 4), 0, 16);
-                        } else if (p.nt_store) __builtin_nontemporal_store(v, (f32x4*)op);
-                        else *(f32x4*)op = v;
-                        if (g.out_bf16_copy)
-                            *(u32x2*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    }
-            }
         return;
     }
 
@@ -1284,12 +1217,6 @@ inline int launch_deep_epi1(bool ta, bool tb, int nb, hipStream_t s, const Param
     if (ta && !tb) return launch_deep_one<128, true, false, 0, 1, 1>(nb, s, p);
     return launch_deep_one<128, true, true, 0, 1, 1>(nb, s, p);
 }
-inline int launch_deep_epi2(bool ta, bool tb, int nb, hipStream_t s, const Params& p) {
-    if (!ta && !tb) return launch_deep_one<128, false, false, 0, 1, 2>(nb, s, p);
-    if (!ta && tb) return launch_deep_one<128, false, true, 0, 1, 2>(nb, s, p);
-    if (ta && !tb) return launch_deep_one<128, true, false, 0, 1, 2>(nb, s, p);
-    return launch_deep_one<128, true, true, 0, 1, 2>(nb, s, p);
-}
 template <int HALF>
 int launch_deep(int wgf, bool ta, bool tb, int sched, int nb, hipStream_t s, const Params& p) {
     if (wgf == 2) return launch_deep_one<HALF, true, true, 2, 0>(nb, s, p);      // in-launch reduction: weight-gradient layout only (UNITE_SPLITK_SEPARATE=0)
@@ -1647,15 +1574,11 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         const bool epi1_ok = kind == 2 && sched == 1 && wgf == 0 && p.splitk == 1 && !g.out_f32 && !g.residual && !g.aux_out && !g.out_bf16_copy &&
                              !want_colsum && (g.act == UNITE_ACT_NONE || g.act == UNITE_ACT_GELU || g.act == UNITE_ACT_QUICKGELU) && p.ngroups == 1 &&
                              (!g.bias || (((uintptr_t)g.bias) & 15) == 0);
-        // form 2: an f32 output (+ residual / old output / bf16 copy) stored straight from the transposed accumulators, no LDS at all
-        const bool epi2_ok = kind == 2 && sched == 1 && wgf == 0 && p.splitk == 1 && g.out_f32 && !g.aux_out && g.act != UNITE_ACT_DGELU && !want_colsum &&
-                             p.ngroups == 1 && (!g.bias || (((uintptr_t)g.bias) & 15) == 0) && (g.ldc & 3) == 0 &&
-                             (!g.residual || (g.residual_bf16 ? (g.ldr & 3) == 0 : (g.ldr & 3) == 0));
-        static const int epi2_env = getenv("UNITE_GEMM_EPI_F32") ? atoi(getenv("UNITE_GEMM_EPI_F32")) : 0;
-        const int want = (g.plan_flags & 16) ? ((g.plan_flags >> 5) & 1) : -1;
-        const int epi = epi1_ok ? (want >= 0 ? want : g_epi_env()) : epi2_ok ? 2 * (want >= 0 ? want : (epi2_env != 0)) : 0;
-        const int rc = epi == 1 ? launch_deep_epi1(g.trans_a != 0, g.trans_b != 0, nb, s, p)
-                     : epi == 2 ? launch_deep_epi2(g.trans_a != 0, g.trans_b != 0, nb, s, p)
+        // (an f32 form of the same idea -- 16-byte stores straight from the transposed accumulators, no LDS: 16 rows x 64 bytes per instruction -- was
+        // built and measured in round 4: bit-identical in its tests and SLOWER, c_proj 308 vs 282 us sustained, out_proj 169 vs 141, the step +0.35 ms;
+        // removed.  Half-line pieces cost more than the LDS round trip saves.)
+        const int epi = epi1_ok ? ((g.plan_flags & 16) ? ((g.plan_flags >> 5) & 1) : g_epi_env()) : 0;
+        const int rc = epi ? launch_deep_epi1(g.trans_a != 0, g.trans_b != 0, nb, s, p)
                      : kind == 2 ? launch_deep<128>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p)
                                  : launch_deep<64>(wgf, g.trans_a != 0, g.trans_b != 0, sched, nb, s, p);
         if (rc != UNITE_OK) return rc;
