@@ -9,6 +9,7 @@
 // output columns of row c16, which leave as one packed 8-byte LDS store.
 // Arithmetic is that of the unfused path (f32 accumulation over k in the same order, + bias, round to bf16, same attention code).
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -21,7 +22,7 @@ constexpr int FQ_LDS = 3 * FQ_STAGE;
 
 __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t* __restrict__ hin, const uint16_t* __restrict__ w_in,
                                                                   const float* __restrict__ b_in, uint16_t* __restrict__ out, int L, int H,
-                                                                  int D, float scale, uint32_t h_bytes, uint32_t w_bytes) {
+                                                                  int D, float scale, uint32_t h_bytes, uint32_t w_bytes, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, G = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -29,7 +30,21 @@ __global__ __launch_bounds__(512, 2) void teacher_qkv_attn_kernel(const uint16_t
     // heads of a frame read its activation rows from one L2 instead of eight
     const int nwg = (int)gridDim.x, bid = blockIdx.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int unit = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int frame = unit / H, h = unit % H;
+    // Inside an XCD's range the units run in blocks of (8 frames x 4 heads), the heads of a frame group block after block: the 32 workgroups an
+    // XCD holds at a time then read 8 x 302 KB of activation rows + 4 x 295 KB of weight rows (3.6 MB, inside its 4-MiB L2), and the next 32 --
+    // the same frames, the next four heads -- find the activation rows still there.  Frame-major (the 12 heads of 2.7 frames at a time) every
+    // set of 32 streams ALL of W (3.5 MB) past 0.8 MB of activations, nothing survives to the next set, and the L2 fetches 433 MB per launch
+    // for 81 MB of operands (rocprofv3 FETCH_SIZE, profiles/r04_clock_notes.txt section 9).  FQ_ORDER 0 keeps the frame-major order (A/B).
+    int frame, h;
+    if (order == 0 || (H & 3)) { frame = unit / H; h = unit % H; }
+    else {
+        const int BT = nwg / H, per_fg = 8 * H;
+        const int fg = unit / per_fg, v = unit - fg * per_fg;
+        const int nf = min(8, BT - fg * 8);                 // the last frame group may be short
+        const int hb = v / (nf * 4), w = v - hb * (nf * 4);
+        frame = fg * 8 + w % nf;
+        h = hb * 4 + w / nf;
+    }
     const int wm = wave >> 2, wn = wave & 3;               // 8 waves: m-tiles wm*7 .. +7 (of 14), n-tiles wn*3 .. +3 (of 12)
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hin, 0, (int)h_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)w_in, 0, (int)w_bytes, 0x00020000);
@@ -248,9 +263,10 @@ extern "C" int unite_teacher_qkv_attn(const void* h, const void* w_in, const flo
         if (e != hipSuccess) return (int)e;
         lds_ok = true;
     }
+    static const int order = getenv("UNITE_TEACHER_FQ_ORDER") ? atoi(getenv("UNITE_TEACHER_FQ_ORDER")) : 1;      // 0: frame-major units, 1: (8 frames x 4 heads) blocks
     const bool prof = unite_prof_begin((hipStream_t)stream);
     hipLaunchKernelGGL(teacher_qkv_attn_kernel, dim3(BT * H), dim3(512), FQ_LDS, (hipStream_t)stream, (const uint16_t*)h, (const uint16_t*)w_in,
-                       b_in, (uint16_t*)out, L, H, D, scale, (uint32_t)h_bytes, (uint32_t)w_bytes);
+                       b_in, (uint16_t*)out, L, H, D, scale, (uint32_t)h_bytes, (uint32_t)w_bytes, order);
     if (prof) unite_prof_end((hipStream_t)stream, 2.0 * BT * L * 3.0 * D * D + 4.0 * BT * H * (double)L * L * 64.0,
                              2.0 * (2.0 * BT * L * D + 3.0 * D * D) + 12.0 * D);      // h in, out, w_in, b_in
     UNITE_LAUNCH_CHECK();
