@@ -45,7 +45,8 @@ struct Params {
                                   // LAST sums the slabs in slice order (+ the old output if accumulate) and writes the tile
     uint32_t* counters;           // one arrival counter per output tile (zero outside a launch)
     float* rowsum_slab;           // f32 [splitk][M] per-slice row sums of op(A) (rowsum_a_out with split-K)
-    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores; 3: no LDS staging writes; 4: staging + barriers only)
+    int32_t debug_skip;           // timing experiments only (UNITE_GEMM_DEBUG_SKIP=1: no epilogue; 2: no global stores).  Keep such switches OUT of the staging loop: two more of them there (round 4's
+                                  // epilogue anatomy) cost the plain 256^2 kernel 12 registers (234 -> 246), i.e. the room beside it on a SIMD
     float* colsum_partial;        // per-tile-row column sums of the stored output (deep kernels only), or NULL
     int32_t nt_store;             // stream the output past the L2 (non-temporal stores) so that it does not evict the operand panels
     int32_t separate_reduce;      // split-K: the slices only write their slabs (and row-sum slabs); splitk_finish_kernel sums them afterwards
@@ -507,8 +508,6 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 
 #pragma unroll
     for (int q = 0; q < (SCHED == 1 ? 7 : 6); ++q) issue(q);
-    f32x4 bias0, bias1;
-    load_bias8(g, n0 + (tid % (TILE / 8)) * 8, bias0, bias1);
 
     const int arow = wm * (HALF / 2), bcol = wn * 32;
     // row sums of op(A): the workgroups of column tile 0 only; the (A half, k-step) pairs of a K-tile are dealt over the waves of a row
@@ -792,6 +791,11 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     // ---- epilogue: HALF rows x TILE columns at a time through an unpadded f32 image in the (now idle) ring (row stride = 0 mod 64
     // banks: 16-column groups are XOR-swizzled by the row's lane-group index so the four groups of a ds_write hit 64 banks): two passes,
     // two barriers each, TILE/32 independent 8-column chunks per thread -> wide (16 B / 32 B per lane) coalesced stores.
+    // the bias chunk: loaded HERE, behind the main loop and ahead of the first staging pass (it lands under the staging writes and their
+    // barrier) -- loaded in front of the main loop it held 8 registers through it, which put the plain 256^2 kernel at 234 registers: two waves
+    // of it then leave 32 of a SIMD's 512, with 226 they leave 48 (a LayerNorm-forward wave of the other stream needs 32)
+    f32x4 bias0, bias1;
+    load_bias8(g, n0 + (tid % (TILE / 8)) * 8, bias0, bias1);
     float* cs = (float*)smem;
     const int G = lane >> 4, c16 = lane & 15;
     constexpr int CPR = TILE / 8;                     // 8-column chunks per row
@@ -807,12 +811,9 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (p.debug_skip == 3) asm volatile("" ::"v"(acc[h][i][nh][j][r]));      // timing experiment: no staging writes
-                        else cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
         __syncthreads();
-        if (p.debug_skip == 4) { __syncthreads(); continue; }      // timing experiment: the staging writes and the barriers only
 #pragma unroll 2
         for (int e = 0; e < TILE / 32; ++e) {
             const int lr = (tid + e * 4 * HALF) / CPR;
