@@ -573,11 +573,13 @@ def test_attention_softmax_spike(ops):
     torch.testing.assert_close(lse.cpu(), lse_ref, atol=2e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1), (256, 197, 12)])
+@pytest.mark.parametrize("BT,L,H", [(5, 197, 2), (3, 197, 12), (2, 224, 16), (4, 193, 1), (256, 197, 12), (37, 197, 12), (11, 197, 16)])
 def test_teacher_fused_qkv_attention_matches_unfused(ops, BT, L, H):
     """unite_teacher_qkv_attn (projection + attention in one workgroup per frame and head, qkv never written) against the two
     kernels it replaces on the same inputs: same f32 accumulation order, same bf16 roundings -> identical bits expected; the
-    assertion allows one bf16 ulp on O(1) outputs for a different MFMA operand order."""
+    assertion allows one bf16 ulp on O(1) outputs for a different MFMA operand order.  The output is pre-filled with NaN: every (frame, head)
+    unit must be written exactly once under the kernel's unit order (blocks of 8 frames x 4 heads inside an XCD's range; 37 and 11 frames leave a
+    short last frame group and ranges that do not end on a block)."""
     D = H * 64
     hx = bf(rnd(BT * L, D, seed=L + H)).to(DEV)
     w = bf(rnd(3 * D, D, seed=7, scale=D ** -0.5)).to(DEV)
