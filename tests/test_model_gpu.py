@@ -62,7 +62,11 @@ def test_teacher_tiny_vs_reference_golden(golden_dir):
     ref_f, ref_a = torch.from_numpy(z["out.feats"]), torch.from_numpy(z["out.attn"])
     assert feats.shape == ref_f.shape and attn.shape == ref_a.shape
     assert cos_min(feats.cpu(), ref_f) >= 0.999
+    # the fixture's CLS attention rows are 4 values of 0.026 .. 0.49 (a 2 x 2 patch grid), not the 1 / 196 of the full model: the bound is
+    # 2.4 % .. 9.6 % of a value; measured on MI355X (round 4): max abs error 4.1e-3, max relative error 2.4 %, feature cosine 0.99994 -- bf16
+    # operands of the score product, nothing to spare
     torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=2e-2)
+    assert cos_min(feats.cpu(), ref_f) >= 0.9998
 
 
 def test_teacher_patch14_vs_oracle():
