@@ -294,7 +294,7 @@ def main():
     ahead = TeacherAhead(teacher, state, dev, 0.8, 'attention') if (a.ahead == 1 and not a.serial and not use_graph) else None
     # the planner weight every GEMM launch of a step carries (unite_gemm_args.plan_sharing): the shared-GPU setting while the teacher runs
     # ahead; --serial profiles the kernels of that default step one at a time and keeps its setting
-    share = [float(os.environ.get("UNITE_GEMM_SHARING", "0.8")) if (a.ahead == 1 and not use_graph) else 0.0]
+    share = [float(os.environ.get("UNITE_GEMM_SHARING", str(TeacherAhead.DEFAULT_SHARING))) if (a.ahead == 1 and not use_graph) else 0.0]
     touts = []
     torch.cuda.synchronize()               # `videos` is complete: the teacher's stream need not wait for the student's at every launch
 
@@ -492,7 +492,7 @@ def main():
                         "(the timed region overlaps the teacher of the next batch, the student and its weight-gradient GEMMs on separate streams, "
                         "which would charge each launch for time it shares with other kernels); same kernels and planner setting as the timed "
                         "region, same numbers as `bench.py --serial` under rocprofv3.  The planner sizes launches for a SHARED GPU "
-                        "(plan_sharing 0.8 in every unite_gemm_args: larger tiles, fewer split-K slices), so these stand-alone durations are longer "
+                        "(plan_sharing 0.9 in every unite_gemm_args: larger tiles, fewer split-K slices), so these stand-alone durations are longer "
                         "than with UNITE_GEMM_SHARING=0 (frac_planned_alone: the same pass planned and measured stand-alone) while the step is shorter: step_frac is the number that counts the whole step"}
     elif world > 1:
         # keep ranks in lock-step with rank 0's profiled passes (every step all-reduces)

@@ -184,13 +184,20 @@ class AheadStream:
     rotate, the ordering of the teacher's INPUTS, and the planner hints its GEMM launches carry (per call, inside unite_gemm_args: no
     process-wide setting is touched, include/unite_hip.h ABI 2)."""
 
+    # planner weight when UNITE_GEMM_SHARING is not set.  Re-measured at the end of round 4 (same call, three interleaved runs each; the
+    # kernels had changed under the 0.8 of round 2): stage 1 ViT-B 20.06 / 20.07 / 20.09 ms at 0.8, 20.06 / 20.05 / 20.08 at 0.85,
+    # 19.96 / 19.91 / 19.94 at 0.9, 21.1 at 0.95 (another box: 20.74 / 20.71 / 20.67 -> 20.45 / 20.49 / 20.47); ViT-L 34.56 / 34.39 -> 33.87 / 33.80;
+    # stage 3 prefers 0.8 (59.83 / 60.35 vs 61.61 / 60.90).  At 0.9 the weight gradients run in 2-4 split-K slices instead of 3-7 and the
+    # proj input gradient and the decoder products on 256^2 tiles.
+    DEFAULT_SHARING = 0.8
+
     def __init__(self, device, n_slots: int):
         self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("UNITE_TEACHER_AHEAD_PRIO", "0")))
         self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_AHEAD_STREAMS", "1")))
         self.gemm_policy = int(os.environ.get("UNITE_TEACHER_PP", "0"))          # -1: whatever the process-wide policy is
         # both phases share the GPU: the GEMM planner weighs the CU time of a launch against its latency (include/unite_hip.h).  The weight
         # travels with every launch of the teacher phase (hints()) and of the student step (student())
-        self.sharing = float(os.environ.get("UNITE_GEMM_SHARING", "0.8"))
+        self.sharing = float(os.environ.get("UNITE_GEMM_SHARING", str(self.DEFAULT_SHARING)))
         self.n_slots = max(2, n_slots)
         self.n = 0
         self._marks = []                   # events on the student's stream, one per launch
@@ -248,6 +255,8 @@ class TeacherAhead(AheadStream):
     GPU (plan_sharing: larger tiles, fewer split-K slices).  Beside a concurrent student the teacher is best left on ONE
     stream (its three frame-range streams: +0.4 ms) and on the tile GEMM kernels (the persistent kernel keeps every CU for a whole launch,
     so nothing of the student slips in between its tiles: +0.2 ms); UNITE_TEACHER_AHEAD_STREAMS / UNITE_TEACHER_PP change that."""
+
+    DEFAULT_SHARING = 0.9                  # stage 1 (AheadStream.DEFAULT_SHARING has the measurements)
 
     def __init__(self, teacher_model, state: StepState, device, mask_ratio, mask_type, clip_input_resolution=224):
         super().__init__(device, int(os.environ.get("UNITE_TEACHER_AHEAD_SLOTS", "3")))
