@@ -960,7 +960,7 @@ def test_stage1_other_clip_loss_types_vs_oracle(kind):
 
 def test_stage1_parity_at_the_benchmark_batch(golden_dir):
     """BASELINE configs[1] AS bench.py TIMES IT -- B = 32, the teacher launched on its own stream (TeacherAhead), every GEMM of both phases
-    planned for a shared GPU (plan_sharing 0.8: other tiles, other split-K factors than at B = 2) -- against sixteen B = 2 steps of the
+    planned for a shared GPU (the stage-1 planner weight, TeacherAhead.DEFAULT_SHARING = 0.9: other tiles, other split-K factors than at B = 2) -- against sixteen B = 2 steps of the
     sequential engine on the same clips and stored mask permutations (drop_path 0): the B = 32 loss is the mean of the sixteen losses to
     2e-5 relative and the gradient the mean of the sixteen gradients to 2e-3 relative L2 (clips are independent, the loss is a mean over
     clips); the first B = 2 step is the golden step of tests/golden/stage1_vitb_cfg1.npz and is held to the REFERENCE's loss (1e-3) here
