@@ -420,6 +420,9 @@ struct FragReader {
     }
 };
 #define UNITE_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+// diagnostics: shader-clock stamps of a workgroup's phases (thread 0, UNITE_GEMM_DEBUG_SKIP=7, eight 64-bit words per workgroup in the caller's
+// workspace; tools/gemm_phase_stamps.py).  Outside every loop.
+#define UNITE_STAMP(k) do { if (p.debug_skip == 7 && threadIdx.x == 0 && g.workspace) ((unsigned long long*)g.workspace)[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define UNITE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // WG: the weight-gradient features -- 1: row sums of op(A) (rowsum_a_out); 2: + the in-launch split-K reduction.  A template parameter, not run-time
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         b_bytes = gi == 1 ? p.more_b_bytes[0] : gi == 2 ? p.more_b_bytes[1] : gi == 3 ? p.more_b_bytes[2] : b_bytes;
         lin0 = gi == 1 ? p.tile_end[0] : gi == 2 ? p.tile_end[1] : gi == 3 ? p.tile_end[2] : 0;
     }
+    UNITE_STAMP(0);
     const int gM = g.M, gN = g.N, gK = g.K, lda = g.lda, ldb = g.ldb;
     const int nbn = (gN + TILE - 1) / TILE, nbm = (gM + TILE - 1) / TILE, nb = nbm * nbn;
     const int tile = (lin - lin0) % nb, slice = (lin - lin0) / nb;
@@ -715,8 +719,10 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     UNITE_LGKM(0);      // the last P4 read fragments nobody uses: they must have arrived before their registers are reused
     UNITE_FENCE();
     }
+    UNITE_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-fill DMAs must not land in the epilogue image
     __syncthreads();
+    UNITE_STAMP(2);
     if (p.debug_skip == 1) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -744,32 +750,44 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 const int gn = n0 + nh * HALF + bcol + j * 16 + 4 * G;
                 bb[nh][j] = (g.bias && gn < gN) ? *(const f32x4*)(g.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        // activation and row scale are decided ONCE, outside the loops (compile-time inside them): left as run-time tests on g.act / g.row_scale per
+        // element they became ~750 scalar branches per workgroup -- 12.7 k of a c_fc tile's 56.7 k cycles (round 4, shader-clock stamps)
+        auto pack_all = [&](auto act_c, auto scale_c) {
+            constexpr int ACT = decltype(act_c)::value;
+            constexpr bool SCALE = decltype(scale_c)::value;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = h * HALF + arow + i * 16 + c16;
-                float sc = 1.f;
-                if (g.row_scale) sc = g.row_scale[min(m0 + row, gM - 1) / g.rows_per_scale];
+                for (int i = 0; i < MT; ++i) {
+                    const int row = h * HALF + arow + i * 16 + c16;
+                    float sc = 1.f;
+                    if constexpr (SCALE) sc = g.row_scale[min(m0 + row, gM - 1) / g.rows_per_scale];
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
+                    for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4 v = acc[h][i][nh][j];
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4 v = acc[h][i][nh][j];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = v[e] + bb[nh][j][e];
-                            if (g.act == UNITE_ACT_GELU) x = gelu_erf(x);
-                            else if (g.act == UNITE_ACT_QUICKGELU) x = quick_gelu(x);
-                            if (g.row_scale) x *= sc;
-                            v[e] = x;
+                            for (int e = 0; e < 4; ++e) {
+                                float x = v[e] + bb[nh][j][e];
+                                if constexpr (ACT == UNITE_ACT_GELU) x = gelu_erf(x);
+                                else if constexpr (ACT == UNITE_ACT_QUICKGELU) x = quick_gelu(x);
+                                if constexpr (SCALE) x *= sc;
+                                v[e] = x;
+                            }
+                            const int unit = (nh * HALF + bcol + j * 16 + 4 * G) >> 2;            // 8-byte unit (four bf16) inside the 512-byte row
+                            const u32x2 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *(u32x2*)(img + row * (TILE * 2) + ((((unit >> 1) ^ (row & 15)) << 4) | ((unit & 1) << 3))) = w;
                         }
-                        const int unit = (nh * HALF + bcol + j * 16 + 4 * G) >> 2;            // 8-byte unit (four bf16) inside the 512-byte row
-                        const u32x2 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2*)(img + row * (TILE * 2) + ((((unit >> 1) ^ (row & 15)) << 4) | ((unit & 1) << 3))) = w;
-                    }
-            }
+                }
+        };
+        const bool scaled = g.row_scale != nullptr;
+        if (g.act == UNITE_ACT_GELU) { if (scaled) pack_all(std::integral_constant<int, UNITE_ACT_GELU>{}, std::true_type{}); else pack_all(std::integral_constant<int, UNITE_ACT_GELU>{}, std::false_type{}); }
+        else if (g.act == UNITE_ACT_QUICKGELU) { if (scaled) pack_all(std::integral_constant<int, UNITE_ACT_QUICKGELU>{}, std::true_type{}); else pack_all(std::integral_constant<int, UNITE_ACT_QUICKGELU>{}, std::false_type{}); }
+        else { if (scaled) pack_all(std::integral_constant<int, UNITE_ACT_NONE>{}, std::true_type{}); else pack_all(std::integral_constant<int, UNITE_ACT_NONE>{}, std::false_type{}); }
+        UNITE_STAMP(3);
         __syncthreads();
+        UNITE_STAMP(4);
         if (p.debug_skip == 4) return;
         constexpr int CH = TILE / 8;                         // 16-byte chunks per row
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
@@ -785,6 +803,9 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
                 else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
             }
         }
+        UNITE_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UNITE_STAMP(6);
         return;
     }
 
