@@ -96,12 +96,29 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
     }
 }
 
+// Feature word of an epilogue: which of its run-time tests are true for a launch.  The epilogue is a template on (KNOWN, VALUE): a test whose bit
+// is in KNOWN is decided at compile time from VALUE, the others stay run-time tests (KNOWN = 0: the generic form).  The 256^2 kernel computes
+// the word once per workgroup and calls a fully-known instantiation for the combinations the training step uses: left as run-time tests inside
+// the chunk loops they were a dozen scalar branches per 8-column chunk (round 4: ~750 per workgroup in the bf16 form, profiles/r04_clock_notes.txt).
+enum : uint32_t { EF_ACT = 7u, EF_SPLIT = 8u, EF_AUXOUT = 16u, EF_SCALE = 32u, EF_RES = 64u, EF_RESBF = 128u, EF_SKIP2 = 256u, EF_OUTF32 = 512u,
+                  EF_ACCUM = 1024u, EF_NT2 = 2048u, EF_NT = 4096u, EF_COPY = 8192u, EF_CSUM = 16384u, EF_ALL = 32767u,
+                  EF_RESPRE = 32768u };      // (caller-only bit) the f32 residual chunk is passed in (r0 | r1): the caller loaded it ahead of the pass
+__device__ __forceinline__ uint32_t epilogue_features(const Params& p, const unite_gemm_args& g, bool csum) {
+    return (uint32_t)g.act | (p.splitk > 1 ? EF_SPLIT : 0u) | (g.aux_out ? EF_AUXOUT : 0u) | (g.row_scale ? EF_SCALE : 0u) | (g.residual ? EF_RES : 0u) |
+           (g.residual_bf16 ? EF_RESBF : 0u) | (p.debug_skip == 2 ? EF_SKIP2 : 0u) | (g.out_f32 ? EF_OUTF32 : 0u) | (g.accumulate ? EF_ACCUM : 0u) |
+           (p.nt_store == 2 ? EF_NT2 : 0u) | (p.nt_store ? EF_NT : 0u) | (g.out_bf16_copy ? EF_COPY : 0u) | (csum ? EF_CSUM : 0u);
+}
+#define UNITE_EF(bit, runtime) ((KNOWN & (bit)) ? ((VALUE & (bit)) != 0u) : (runtime))
+#define UNITE_EF_ACT(a) ((KNOWN & EF_ACT) ? ((VALUE & EF_ACT) == (uint32_t)(a)) : (g.act == (a)))
+
 // Epilogue for 8 consecutive output columns of one row (f32 accumulators v0|v1): see unite_hip.h for the order of operations.
 // The bias chunk (b0|b1) is loaded by the caller ONCE per tile, ahead of the stores: vmcnt retires in issue order, so a
 // load issued between the stores of two passes could only be waited for together with every store before it.
+template <uint32_t KNOWN = 0u, uint32_t VALUE = 0u>
 __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm_args& g, int slice, int gm, int gn, f32x4 v0, f32x4 v1,
-                                               f32x4 b0, f32x4 b1, float* csum = nullptr) {
-    if (p.splitk > 1) {      // raw partial product -> slab, write-through (sc1): the tile's last slice to finish reads it in this launch
+                                               f32x4 b0, f32x4 b1, float* csum = nullptr, f32x4 pr0 = (f32x4){0.f, 0.f, 0.f, 0.f},
+                                               f32x4 pr1 = (f32x4){0.f, 0.f, 0.f, 0.f}) {
+    if (UNITE_EF(EF_SPLIT, p.splitk > 1)) {      // raw partial product -> slab, write-through (sc1): the tile's last slice to finish reads it in this launch
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)slice * g.M * g.N), 0, 0x7FFFFFF0, 0x00020000);
         const uint32_t off = (uint32_t)(((size_t)gm * g.N + gn) * 4);
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v0[0]), __float_as_uint(v0[1]), __float_as_uint(v0[2]), __float_as_uint(v0[3])}, rs, off, 0, 16);
@@ -113,17 +130,17 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
     for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-    if (g.act == UNITE_ACT_GELU) {
-        if (g.aux_out) {
+    if (UNITE_EF_ACT(UNITE_ACT_GELU)) {
+        if (UNITE_EF(EF_AUXOUT, g.aux_out != nullptr)) {
             u32x4 z = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             *(u32x4*)((uint16_t*)g.aux_out + (size_t)gm * g.ld_aux_out + gn) = z;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-    } else if (g.act == UNITE_ACT_QUICKGELU) {
+    } else if (UNITE_EF_ACT(UNITE_ACT_QUICKGELU)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
-    } else if (g.act == UNITE_ACT_DGELU) {
+    } else if (UNITE_EF_ACT(UNITE_ACT_DGELU)) {
         const u32x4 z = *(const u32x4*)((const uint16_t*)g.aux_in + (size_t)gm * g.ld_aux_in + gn);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -131,19 +148,22 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
             v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(z[e] & 0xFFFF0000u));
         }
     }
-    if (g.row_scale) {
+    if (UNITE_EF(EF_SCALE, g.row_scale != nullptr)) {
         const float sc = g.row_scale[gm / g.rows_per_scale];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= sc;
     }
-    if (g.residual) {
-        if (g.residual_bf16) {
+    if (UNITE_EF(EF_RES, g.residual != nullptr)) {
+        if (UNITE_EF(EF_RESBF, g.residual_bf16 != 0)) {
             const u32x4 r = *(const u32x4*)((const uint16_t*)g.residual + (size_t)gm * g.ldr + gn);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[2 * e] += __uint_as_float(r[e] << 16);
                 v[2 * e + 1] += __uint_as_float(r[e] & 0xFFFF0000u);
             }
+        } else if ((KNOWN & EF_RESPRE) && (VALUE & EF_RESPRE)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += pr0[e]; v[4 + e] += pr1[e]; }
         } else {
             const float* rp = (const float*)g.residual + (size_t)gm * g.ldr + gn;
             const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
@@ -151,23 +171,23 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
             for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
         }
     }
-    if (p.debug_skip == 2) {      // timing experiment: everything but the stores
+    if (UNITE_EF(EF_SKIP2, p.debug_skip == 2)) {      // timing experiment: everything but the stores
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
         return;
     }
-    if (g.out_f32) {
+    if (UNITE_EF(EF_OUTF32, g.out_f32 != 0)) {
         float* op = (float*)g.out + (size_t)gm * g.ldc + gn;
-        if (g.accumulate) {
+        if (UNITE_EF(EF_ACCUM, g.accumulate != 0)) {
             const f32x4 o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
         }
-        if (p.nt_store == 2) {       // write-through, line dropped from the XCD's L2 (sc1): the output must not evict A/B panels
+        if (UNITE_EF(EF_NT2, p.nt_store == 2)) {       // write-through, line dropped from the XCD's L2 (sc1): the output must not evict A/B panels
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
             const uint32_t off = (uint32_t)(((size_t)gm * g.ldc + gn) * 4);
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ro, off, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, ro, off + 16, 0, 16);
-        } else if (p.nt_store) {
+        } else if (UNITE_EF(EF_NT, p.nt_store != 0)) {
             __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, (f32x4*)op);
             __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, (f32x4*)(op + 4));
         } else {
@@ -176,18 +196,18 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
         }
     } else {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        if (p.nt_store == 2) {
+        if (UNITE_EF(EF_NT2, p.nt_store == 2)) {
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
-        } else if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
+        } else if (UNITE_EF(EF_NT, p.nt_store != 0)) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
         else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
     }
-    if (g.out_bf16_copy) {
+    if (UNITE_EF(EF_COPY, g.out_bf16_copy != nullptr)) {
         u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         *(u32x4*)((uint16_t*)g.out_bf16_copy + (size_t)gm * g.ld_copy + gn) = o;
     }
-    if (csum) {      // column sums of what was stored (a later colsum over a bf16 output would read the rounded values)
-        if (g.out_f32) {
+    if (UNITE_EF(EF_CSUM, csum != nullptr)) {      // column sums of what was stored (a later colsum over a bf16 output would read the rounded values)
+        if (UNITE_EF(EF_OUTF32, g.out_f32 != 0)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) csum[e] += v[e];
         } else {
@@ -821,8 +841,32 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     const int G = lane >> 4, c16 = lane & 15;
     constexpr int CPR = TILE / 8;                     // 8-column chunks per row
     const int ccol = (tid % CPR) * 8;                 // this thread's column chunk is the same in every pass
+    // the chunk loop of one pass with the epilogue's tests decided at compile time (`known` = EF_ALL) or at run time (0)
+    auto chunks = [&](auto known_c, auto value_c, int h, float* csum) {
+        constexpr uint32_t KN = decltype(known_c)::value, VL = decltype(value_c)::value;
+#pragma unroll 2
+        for (int e = 0; e < TILE / 32; ++e) {
+            const int lr = (tid + e * 4 * HALF) / CPR;
+            const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
+            const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
+            if (gm < g.M && gn < g.N) epilogue_chunk<KN, VL>(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1, csum);
+        }
+    };
+    // the same loop, FOUR chunks in flight, for the f32 + f32-residual forms (teacher out_proj / c_proj, student proj / fc2): their residual
+    // chunks come from memory, and two at a time every pair waits for its own round trip -- 19 k of c_proj's 172 k cycles per pass (stamps)
+    auto chunks4 = [&](auto value_c, int h) {
+        constexpr uint32_t VL = decltype(value_c)::value;
+#pragma unroll 4
+        for (int e = 0; e < TILE / 32; ++e) {
+            const int lr = (tid + e * 4 * HALF) / CPR;
+            const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
+            const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
+            if (gm < g.M && gn < g.N) epilogue_chunk<EF_ALL, VL>(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1, nullptr);
+        }
+    };
     float csum_v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float* const csum = p.colsum_partial ? csum_v : nullptr;
+    const uint32_t fw = epilogue_features(p, g, csum != nullptr);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -834,16 +878,30 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         cs[(arow + i * 16 + 4 * G + r) * TILE + ((nh * HALF + bcol + j * 16 + c16) ^ (G << 4))] = acc[h][i][nh][j][r];
+        if (h == 0) UNITE_STAMP(3);
         __syncthreads();
-#pragma unroll 2
-        for (int e = 0; e < TILE / 32; ++e) {
-            const int lr = (tid + e * 4 * HALF) / CPR;
-            const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
-            const float* cp = cs + lr * TILE + (ccol ^ (((lr >> 2) & 3) << 4));
-            if (gm < g.M && gn < g.N) epilogue_chunk(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1, csum);
-        }
+        if (h == 0) UNITE_STAMP(4);
+        using KA = std::integral_constant<uint32_t, EF_ALL>;
+#define UNITE_HOT(v) if (fw == (uint32_t)(v)) chunks(KA{}, std::integral_constant<uint32_t, (uint32_t)(v)>{}, h, nullptr); else
+        if (fw == (EF_OUTF32 | EF_RES)) chunks4(std::integral_constant<uint32_t, EF_OUTF32 | EF_RES>{}, h);              // teacher out_proj / c_proj
+        else if (fw == (EF_OUTF32 | EF_RES | EF_SCALE)) chunks4(std::integral_constant<uint32_t, EF_OUTF32 | EF_RES | EF_SCALE>{}, h);   // student proj / fc2
+        else
+        UNITE_HOT(UNITE_ACT_DGELU)                                           // fc2 input gradient x GELU'(z), bf16
+        UNITE_HOT(UNITE_ACT_DGELU | EF_NT2 | EF_NT)
+        UNITE_HOT(UNITE_ACT_GELU | EF_AUXOUT)                                // fc1 forward: z saved, a = GELU(z), bf16
+        UNITE_HOT(UNITE_ACT_GELU | EF_AUXOUT | EF_NT2 | EF_NT)
+        UNITE_HOT(EF_OUTF32)                                                 // plain f32 products (weight gradients without split-K, ...)
+        UNITE_HOT(EF_OUTF32 | EF_ACCUM)
+        UNITE_HOT(EF_SPLIT | EF_OUTF32)                                      // split-K slices: raw slabs
+        UNITE_HOT(EF_SPLIT | EF_OUTF32 | EF_ACCUM)
+        UNITE_HOT(0u)                                                        // plain bf16
+        UNITE_HOT(EF_NT2 | EF_NT)
+        chunks(std::integral_constant<uint32_t, 0u>{}, std::integral_constant<uint32_t, 0u>{}, h, csum);
+#undef UNITE_HOT
+        if (h == 0) UNITE_STAMP(5);
         __syncthreads();
     }
+    UNITE_STAMP(6);
     if (csum) {
         // this thread's sums cover its rows of column chunk ccol; the 4 * HALF / CPR threads of a column chunk meet in LDS and
         // leave ONE partial row per tile: colsum_partial[tile row][n] (summed over tile rows by colsum_rows_kernel, fixed order)
