@@ -811,18 +811,26 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         if (p.debug_skip == 4) return;
         constexpr int CH = TILE / 8;                         // 16-byte chunks per row
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
+        // the store kind is decided once, outside the loop (see pack_all)
+        auto store_all = [&](auto kind_c) {
+            constexpr int KIND = decltype(kind_c)::value;      // 0 plain, 1 non-temporal, 2 write-through (sc1), 3 none (timing)
 #pragma unroll 4
-        for (int e = 0; e < TILE * CH / (4 * HALF); ++e) {
-            const int idx = tid + e * 4 * HALF, row = idx / CH, ch = idx % CH;
-            const u32x4 o = *(const u32x4*)(img + row * (TILE * 2) + ((ch ^ (row & 15)) << 4));
-            const int gm = m0 + row, gn = n0 + ch * 8;
-            if (gm < gM && gn < gN) {
-                if (p.debug_skip == 2) asm volatile("" ::"v"(o));
-                else if (p.nt_store == 2) __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
-                else if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
-                else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+            for (int e = 0; e < TILE * CH / (4 * HALF); ++e) {
+                const int idx = tid + e * 4 * HALF, row = idx / CH, ch = idx % CH;
+                const u32x4 o = *(const u32x4*)(img + row * (TILE * 2) + ((ch ^ (row & 15)) << 4));
+                const int gm = m0 + row, gn = n0 + ch * 8;
+                if (gm < gM && gn < gN) {
+                    if constexpr (KIND == 3) asm volatile("" ::"v"(o));
+                    else if constexpr (KIND == 2) __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
+                    else if constexpr (KIND == 1) __builtin_nontemporal_store(o, (u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn));
+                    else *(u32x4*)((uint16_t*)g.out + (size_t)gm * g.ldc + gn) = o;
+                }
             }
-        }
+        };
+        if (p.debug_skip == 2) store_all(std::integral_constant<int, 3>{});
+        else if (p.nt_store == 2) store_all(std::integral_constant<int, 2>{});
+        else if (p.nt_store) store_all(std::integral_constant<int, 1>{});
+        else store_all(std::integral_constant<int, 0>{});
         UNITE_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UNITE_STAMP(6);
