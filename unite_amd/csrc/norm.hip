@@ -100,8 +100,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
 
 // ------------------------------------------------------------------------------------ backward
 // dx = rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat));  dgamma = sum_rows dy*xhat; dbeta = sum_rows dy
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
+// FLAGS: -1 = every option is a run-time test (generic); otherwise bit 0 dy is f32, bit 1 a residual gradient is added, bit 2 the f32 result is
+// stored, bit 3 the bf16 copy (+ its column sums) is stored, bit 4 a row scale applies to the copy -- known at compile time for the combinations the
+// training steps use (round 4: run-time tests on kernel arguments inside unrolled per-element loops had turned out to be a branch per element in
+// the GEMM epilogues, profiles/r04_clock_notes.txt section 18)
+template <int NV, int FLAGS = -1>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32_rt, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ dx_residual,
                                                             float* __restrict__ dx_out, void* __restrict__ dx_bf16,
@@ -109,6 +113,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             float* __restrict__ partial, int M, int D) {
     __shared__ float red[4][3][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool dy_f32 = FLAGS >= 0 ? (FLAGS & 1) != 0 : dy_f32_rt != 0;
+    if (FLAGS >= 0) {                                      // the pointers a known combination does not use are dead from here on
+        if (!(FLAGS & 2)) dx_residual = nullptr;
+        if (!(FLAGS & 4)) dx_out = nullptr;
+        if (!(FLAGS & 8)) dx_bf16 = nullptr;
+        if (!(FLAGS & 16)) row_scale = nullptr;
+    }
+    const bool has_res = FLAGS >= 0 ? (FLAGS & 2) != 0 : dx_residual != nullptr;
+    const bool has_out = FLAGS >= 0 ? (FLAGS & 4) != 0 : dx_out != nullptr;
+    const bool has_bf = FLAGS >= 0 ? (FLAGS & 8) != 0 : dx_bf16 != nullptr;
+    const bool has_sc = FLAGS >= 0 ? (FLAGS & 16) != 0 : row_scale != nullptr;
     f32x4 gam[NV], dg[NV], db[NV], ds[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         if (row >= M) break;
         f32x4 xv[NV], dyv[NV], resv[NV];
         load_row<NV>(x + (size_t)row * ldx, D, lane, xv);
-        if (dx_residual) load_row<NV>(dx_residual + (size_t)row * D, D, lane, resv);      // with the other loads: one memory round trip per row
+        if (has_res) load_row<NV>(dx_residual + (size_t)row * D, D, lane, resv);      // with the other loads: one memory round trip per row
         if (dy_f32) load_row<NV>((const float*)dy + (size_t)row * D, D, lane, dyv);
         else {
 #pragma unroll
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
             }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
-        const float sc = row_scale ? row_scale[row / rows_per_scale] : 1.0f;
+        const float sc = has_sc ? row_scale[row / rows_per_scale] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -159,12 +174,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gam[i][e] * dyv[i][e] - s1 - xv[i][e] * s2);
-                if (dx_residual) {
+                if (has_res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += resv[i][e];
                 }
-                if (dx_out) *(f32x4*)(dx_out + (size_t)row * D + c) = o;
-                if (dx_bf16) {
+                if (has_out) *(f32x4*)(dx_out + (size_t)row * D + c) = o;
+                if (has_bf) {
                     const u32x2 w = (u32x2){pack_bf16x2(sc * o[0], sc * o[1]), pack_bf16x2(sc * o[2], sc * o[3])};
                     *(u32x2*)((uint16_t*)dx_bf16 + (size_t)row * D + c) = w;
                     // column sums of exactly what the consuming GEMMs read (its bias gradient)
@@ -497,8 +512,16 @@ extern "C" int unite_layernorm_bwd(const void* dy, int32_t dy_f32, const float* 
     hipStream_t s = (hipStream_t)stream;
     const int nb = (M + bwd_rows_per_block(M) - 1) / bwd_rows_per_block(M);
     if (dxsum && !dx_bf16) return UNITE_EINVAL;
-    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma,
-                                      dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D));
+    // the option combinations of the training steps as compile-time forms (ViT blocks: bf16 dy, residual gradient, f32 + bf16 results, with or
+    // without a drop-path scale), anything else through the generic form
+    const int flags = (dy_f32 ? 1 : 0) | (dx_residual ? 2 : 0) | (dx_out ? 4 : 0) | (dx_bf16 ? 8 : 0) | (row_scale ? 16 : 0);
+#define LN_BWD_FORM(F) DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<NV, F>), dim3(nb), dim3(256), 0, s, dy, dy_f32, x, ldx, mean, rstd, gamma, \
+                                                         dx_residual, dx_out, dx_bf16, row_scale, rows_per_scale, (float*)workspace, M, D))
+    if (flags == (2 | 4 | 8)) { LN_BWD_FORM(14); }
+    else if (flags == (2 | 4 | 8 | 16)) { LN_BWD_FORM(30); }
+    else if (flags == (2 | 4)) { LN_BWD_FORM(6); }
+    else { LN_BWD_FORM(-1); }
+#undef LN_BWD_FORM
     UNITE_LAUNCH_CHECK();
     if (dgamma || dbeta || dxsum) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32, 3), dim3(256), 0, s, (const float*)workspace, nb, D, dgamma,
