@@ -46,13 +46,17 @@ const char* unite_target_arch(void);
  *   v += bias[n]                                   (bias != NULL)
  *   act == UNITE_ACT_GELU      : if aux_out: aux_out[m,n] = bf16(v); v = gelu_erf(v)
  *   act == UNITE_ACT_QUICKGELU : v = v * sigmoid(1.702 v)                       (clip.py:29-31)
- *   act == UNITE_ACT_DGELU     : v *= gelu_erf'(aux_in[m,n])                    (backward of fc1)
+ *   act == UNITE_ACT_DGELU     : v *= gelu_erf'(aux_in[m,n])                    (backward of fc1 from the saved pre-activation)
+ *   act == UNITE_ACT_GELU_DSAVE: aux_out[m,n] = q16(gelu_erf'(v)); v = gelu_erf(v)    (aux_out required: the derivative is saved, not the input)
+ *   act == UNITE_ACT_MULAUX    : v *= unq16(aux_in[m,n])                        (backward of fc1 from the saved derivative)
+ *       q16(d) = round(65535 (d + 0.25) / 2) as an unsigned 16-bit number (the derivative lies in [-0.13, 1.13]); unq16(q) = 2 q / 65535 - 0.25.
+ *       The buffer has the size and leading dimension of a bf16 one; its contents are opaque to the caller.
  *   v *= row_scale[m / rows_per_scale]             (row_scale != NULL; stochastic depth)
  *   v += residual[m,n]                             (residual != NULL; f32, or bf16 if residual_bf16 != 0; ld = ldr)
  *   v += out[m,n]                                  (accumulate != 0, f32 out only)
  *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given;  colsum_out (+)= column sums of out.
  * ------------------------------------------------------------------------------------ */
-enum { UNITE_ACT_NONE = 0, UNITE_ACT_GELU = 1, UNITE_ACT_QUICKGELU = 2, UNITE_ACT_DGELU = 3 };
+enum { UNITE_ACT_NONE = 0, UNITE_ACT_GELU = 1, UNITE_ACT_QUICKGELU = 2, UNITE_ACT_DGELU = 3, UNITE_ACT_GELU_DSAVE = 4, UNITE_ACT_MULAUX = 5 };
 
 typedef struct unite_gemm_args {
     int32_t M, N, K;

@@ -392,6 +392,37 @@ def test_gemm_persistent_epilogues(ops, persistent_everywhere):
     torch.testing.assert_close(out2.float().cpu(), (a.float() @ w2.float()) * zg.grad, atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(330, 264, 192), (2048 + 72, 1536, 768)])
+def test_gemm_saved_gelu_derivative(ops, M, N, K):
+    """fc1 saves GELU'(z) instead of z (UNITE_ACT_GELU_DSAVE) and the fc2 input gradient multiplies by it (UNITE_ACT_MULAUX): both against
+    fp32 autograd on the same bf16-rounded operands (reference: the nn.GELU of modeling_finetune.py:61-83's Mlp under autograd), at a shape
+    the small tile kernels serve through the generic epilogue and at one the 256^2 kernel serves with its compiled forms."""
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    acc = (a.float() @ w.float().t() + bias).requires_grad_(True)
+    y = O.gelu_erf(acc)
+    y.sum().backward()
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), act=ops.ACT_GELU_DSAVE, aux_out=d)
+    torch.testing.assert_close(out.float().cpu(), y.detach(), atol=2e-2, rtol=1e-2)
+    dq = (d.view(torch.int16).to(torch.int32) & 0xFFFF).float().cpu() * (2.0 / 65535.0) - 0.25      # 16-bit fixed point (unite_hip.h)
+    torch.testing.assert_close(dq, acc.grad, atol=4e-5, rtol=0)
+    # the same CDF serves both forms: the saved-z form gives the same activation (to a bf16 ulp: the planner may pick another kernel for it)
+    out1 = torch.empty_like(out)
+    ops.gemm(a.to(DEV), w.to(DEV), out1, bias=bias.to(DEV), act=ops.ACT_GELU, aux_out=torch.empty_like(d))
+    torch.testing.assert_close(out.float(), out1.float(), atol=1e-2, rtol=8e-3)
+    # backward: dz = (dy @ W2) * saved derivative, k-strided B as in the fc2 input gradient
+    w2 = bf(rnd(K, N, seed=6, scale=K ** -0.5))
+    out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a.to(DEV), w2.to(DEV), out2, trans_b=True, act=ops.ACT_MULAUX, aux_in=d)
+    torch.testing.assert_close(out2.float().cpu(), (a.float() @ w2.float()) * dq, atol=2e-2, rtol=1e-2)
+    with pytest.raises(Exception):
+        ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), act=ops.ACT_GELU_DSAVE)          # the derivative has nowhere to go
+    with pytest.raises(Exception):
+        ops.gemm(a.to(DEV), w2.to(DEV), out2, trans_b=True, act=ops.ACT_MULAUX)
+
+
 def test_gemm_persistent_matches_tile_kernels(ops, persistent_everywhere):
     """the teacher's c_fc shape (M = 50 432: 4 728 tiles, 18-19 per workgroup) against the same product in four row chunks that are too
     small for the persistent kernel's planner threshold... both paths accumulate k in the same order within a K-tile; allow one bf16 ulp."""

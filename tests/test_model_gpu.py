@@ -207,6 +207,26 @@ def test_student_tiny_vs_reference_golden(golden_dir):
         assert d.mean() <= 0.05 * lr, (k, (d.mean() / lr).item())
 
 
+def test_saved_gelu_derivative_equals_recomputed_tiny(golden_dir):
+    """UNITE_GELU_DSAVE: the MLP's backward from the derivative the forward saved (16-bit fixed point) against the default path, which recomputes
+    GELU' from the saved bf16 pre-activation -- same loss (the forward values are the same), gradients within 5e-3, and both within the golden bound."""
+    z = _load(golden_dir, "student_tiny.npz")
+    grads = []
+    for dsave in (False, True):
+        s, _ = build_tiny()
+        s.load_state_dict(fill_state_dict(student_shapes(TINY_S), int(z["in.seed_weights"])))
+        s = s.to(DEV).train()
+        s.runtime().gelu_dsave = dsave
+        out = s(torch.from_numpy(z["in.videos"]).to(DEV), torch.from_numpy(z["in.mask"]).to(DEV), clip_only=True)
+        loss = (2 - 2 * (out * torch.from_numpy(z["out.targets"]).to(DEV)).sum(dim=-1)).mean()
+        assert abs(loss.item() - float(z["out.loss"])) <= 1e-3 * abs(float(z["out.loss"]))
+        loss.backward()
+        for k, p in s.named_parameters():
+            assert rel_l2(p.grad.cpu(), torch.from_numpy(z["g." + k])) <= 5e-2, (dsave, k)
+        grads.append(s.runtime().fp.grad.clone())
+    assert rel_l2(grads[1], grads[0]) <= 5e-3
+
+
 def test_parameters_without_gradient_follow_torch_semantics():
     """torch semantics of `p.grad is None`: (a) blocks above the highest tap are not executed under clip_only
     (modeling_adaptation.py:165-166) -- their parameters must not be weight-decayed or moment-updated and must not enter the gradient

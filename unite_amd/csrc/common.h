@@ -92,6 +92,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
     return __builtin_fmaf(x, pdf, norm_cdf(x));
 }
+// gelu_erf(x) and gelu_erf'(x) from ONE evaluation of the normal CDF: the forward fc1 epilogue saves the derivative (UNITE_ACT_GELU_DSAVE), so
+// that the backward epilogue is a decode + multiply (UNITE_ACT_MULAUX) instead of ~25 VALU instructions per element.
+// The derivative lies in [-0.129, 1.129]; it is saved as a 16-bit fixed-point number q = round(65535 (d + 0.25) / 2) (v_cvt_pknorm_u16_f32):
+// absolute error <= 1.6e-5, where bf16 would carry 2e-3 relative and recomputing from the bf16-rounded z carries 5e-4 (tools/gelu_dsave_error.py).
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+    const float c = norm_cdf(x);
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    y = x * c;
+    dy = __builtin_fmaf(x, pdf, c);
+}
+__device__ __forceinline__ uint32_t pack_dgelu_x2(float d0, float d1) {
+    const auto q = __builtin_amdgcn_cvt_pknorm_u16(__builtin_fmaf(d0, 0.5f, 0.125f), __builtin_fmaf(d1, 0.5f, 0.125f));
+    return __builtin_bit_cast(uint32_t, q);
+}
+__device__ __forceinline__ float unpack_dgelu_lo(uint32_t q) { return __builtin_fmaf((float)(q & 0xFFFFu), 2.0f / 65535.0f, -0.25f); }
+__device__ __forceinline__ float unpack_dgelu_hi(uint32_t q) { return __builtin_fmaf((float)(q >> 16), 2.0f / 65535.0f, -0.25f); }
 // x * sigmoid(1.702 x) with v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions)
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
 

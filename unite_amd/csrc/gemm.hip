@@ -147,6 +147,19 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
             v[2 * e] *= gelu_erf_grad(__uint_as_float(z[e] << 16));
             v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(z[e] & 0xFFFF0000u));
         }
+    } else if (UNITE_EF_ACT(UNITE_ACT_GELU_DSAVE)) {      // the derivative is saved (16-bit fixed point) instead of the pre-activation: one CDF evaluation serves both
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_erf_both(v[e], v[e], d[e]);
+        *(u32x4*)((uint16_t*)g.aux_out + (size_t)gm * g.ld_aux_out + gn) =
+            (u32x4){pack_dgelu_x2(d[0], d[1]), pack_dgelu_x2(d[2], d[3]), pack_dgelu_x2(d[4], d[5]), pack_dgelu_x2(d[6], d[7])};
+    } else if (UNITE_EF_ACT(UNITE_ACT_MULAUX)) {
+        const u32x4 z = *(const u32x4*)((const uint16_t*)g.aux_in + (size_t)gm * g.ld_aux_in + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= unpack_dgelu_lo(z[e]);
+            v[2 * e + 1] *= unpack_dgelu_hi(z[e]);
+        }
     }
     if (UNITE_EF(EF_SCALE, g.row_scale != nullptr)) {
         const float sc = g.row_scale[gm / g.rows_per_scale];
@@ -862,9 +875,10 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
     };
     // the same loop, FOUR chunks in flight, for the f32 + f32-residual forms (teacher out_proj / c_proj, student proj / fc2): their residual
     // chunks come from memory, and two at a time every pair waits for its own round trip -- 19 k of c_proj's 172 k cycles per pass (stamps)
-    auto chunks4 = [&](auto value_c, int h) {
+    auto chunksU = [&](auto value_c, auto unroll_c, int h) {
         constexpr uint32_t VL = decltype(value_c)::value;
-#pragma unroll 4
+        constexpr int U = decltype(unroll_c)::value;
+#pragma unroll U
         for (int e = 0; e < TILE / 32; ++e) {
             const int lr = (tid + e * 4 * HALF) / CPR;
             const int gm = m0 + h * HALF + lr, gn = n0 + ccol;
@@ -872,6 +886,7 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
             if (gm < g.M && gn < g.N) epilogue_chunk<EF_ALL, VL>(p, g, slice, gm, gn, *(const f32x4*)cp, *(const f32x4*)(cp + 4), bias0, bias1, nullptr);
         }
     };
+    auto chunks4 = [&](auto value_c, int h) { chunksU(value_c, std::integral_constant<int, 4>{}, h); };
     float csum_v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float* const csum = p.colsum_partial ? csum_v : nullptr;
     const uint32_t fw = epilogue_features(p, g, csum != nullptr);
@@ -898,6 +913,10 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
         UNITE_HOT(UNITE_ACT_DGELU | EF_NT2 | EF_NT)
         UNITE_HOT(UNITE_ACT_GELU | EF_AUXOUT)                                // fc1 forward: z saved, a = GELU(z), bf16
         UNITE_HOT(UNITE_ACT_GELU | EF_AUXOUT | EF_NT2 | EF_NT)
+        UNITE_HOT(UNITE_ACT_MULAUX)                                          // fc2 input gradient x the saved GELU'(z), bf16
+        UNITE_HOT(UNITE_ACT_MULAUX | EF_NT2 | EF_NT)
+        UNITE_HOT(UNITE_ACT_GELU_DSAVE | EF_AUXOUT)                          // fc1 forward: GELU'(z) saved, a = GELU(z), bf16
+        UNITE_HOT(UNITE_ACT_GELU_DSAVE | EF_AUXOUT | EF_NT2 | EF_NT)
         UNITE_HOT(EF_OUTF32)                                                 // plain f32 products (weight gradients without split-K, ...)
         UNITE_HOT(EF_OUTF32 | EF_ACCUM)
         UNITE_HOT(EF_SPLIT | EF_OUTF32)                                      // split-K slices: raw slabs
@@ -1395,8 +1414,8 @@ inline double algo_bytes(const unite_gemm_args& g) {
     double b = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + mn * (g.out_f32 ? 4.0 : 2.0);
     if (g.bias) b += 4.0 * g.N;
     if (g.residual) b += mn * (g.residual_bf16 ? 2.0 : 4.0);
-    if (g.act == UNITE_ACT_DGELU && g.aux_in) b += mn * 2.0;
-    if (g.act == UNITE_ACT_GELU && g.aux_out) b += mn * 2.0;
+    if ((g.act == UNITE_ACT_DGELU || g.act == UNITE_ACT_MULAUX) && g.aux_in) b += mn * 2.0;
+    if ((g.act == UNITE_ACT_GELU || g.act == UNITE_ACT_GELU_DSAVE) && g.aux_out) b += mn * 2.0;
     if (g.accumulate) b += mn * 4.0;
     if (g.out_bf16_copy) b += mn * 2.0;
     return b;
@@ -1412,7 +1431,9 @@ int check_problem(const unite_gemm_args& g, int64_t& a_bytes, int64_t& b_bytes) 
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.out)) return UNITE_EINVAL;
     if ((g.trans_a ? (g.M & 7) : (g.K & 7)) || (g.trans_b ? 0 : (g.K & 7))) return UNITE_EINVAL;
     if (g.accumulate && !g.out_f32) return UNITE_EINVAL;
-    if (g.act == UNITE_ACT_DGELU && (!g.aux_in || (g.ld_aux_in & 7))) return UNITE_EINVAL;
+    if (g.act < UNITE_ACT_NONE || g.act > UNITE_ACT_MULAUX) return UNITE_EINVAL;
+    if ((g.act == UNITE_ACT_DGELU || g.act == UNITE_ACT_MULAUX) && (!g.aux_in || (g.ld_aux_in & 7) || !aligned16(g.aux_in))) return UNITE_EINVAL;
+    if (g.act == UNITE_ACT_GELU_DSAVE && !g.aux_out) return UNITE_EINVAL;
     if (g.aux_out && (g.ld_aux_out & 7)) return UNITE_EINVAL;
     if (g.row_scale && g.rows_per_scale <= 0) return UNITE_EINVAL;
     if (g.residual && ((g.ldr & (g.residual_bf16 ? 7 : 3)) || !aligned16(g.residual))) return UNITE_EINVAL;

@@ -572,6 +572,7 @@ int unite_gemm_pp_supported(const unite_gemm_args& g) {
         if (g.row_scale && (g.rows_per_scale < 2 || g.rows_per_scale > 4096 || g.M >= (1 << 20))) return 0;
     } else {
         if (g.row_scale) return 0;
+        if (g.act > UNITE_ACT_DGELU) return 0;                       // the saved-derivative forms are the tile kernels' (gemm.hip)
         if (g.residual && (!g.residual_bf16 || g.act != UNITE_ACT_NONE || g.aux_out || (g.ldr & 7) || !aligned16p(g.residual) ||
                            ((int64_t)(g.M - 1) * g.ldr + g.N) * 2 >= mx)) return 0;
         if (g.act == UNITE_ACT_DGELU && (!g.aux_in || !aligned16p(g.aux_in))) return 0;

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_DGELU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
 F32 = torch.float32
 

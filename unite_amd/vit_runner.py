@@ -81,6 +81,11 @@ class ViTRunner:
         # CU time, not latency, is what they cost an overlapped step: UNITE_WGRAD_SHARING pins the weight for A/B runs
         self.wgrad_sharing = float(os.environ["UNITE_WGRAD_SHARING"]) if "UNITE_WGRAD_SHARING" in os.environ else None
         self.wgrad_rowsum = os.environ.get("UNITE_WGRAD_ROWSUM", "1") != "0"      # bias gradients beside the weight-gradient products (0: separate column-sum kernels)
+        # UNITE_GELU_DSAVE=1: fc1 saves GELU'(z) (16-bit fixed point, error 1.6e-5) instead of z, and the fc2 input-gradient epilogue multiplies by it:
+        # one CDF evaluation in the forward serves both, where recomputing GELU' from the bf16 z costs the backward epilogue ~25 VALU instructions
+        # per element.  Measured (round 4, profiles/r04_clock_notes.txt section 19): fc2 input gradient 58.9 against 66.7 us on one box and equal
+        # on another (it is HBM-bound by the saved tensor either way), fc1 forward + 4.5 us, the step equal within 0.01 ms -> off by default.
+        self.gelu_dsave = os.environ.get("UNITE_GELU_DSAVE", "0") != "0"
         self.fused_colsum = os.environ.get("UNITE_FUSED_COLSUM", "0") != "0"      # fc1 bias gradient out of the fc2-dgrad GEMM epilogue (no gain: the separate colsum hides on the side stream)
         self._side = None
         self.step_params = None          # graph_step.StepParams: stochastic depth then reads its seed from device memory
@@ -201,7 +206,7 @@ class ViTRunner:
             ops.layernorm_fwd(x1, w["norm2.weight"], w["norm2.bias"], self.eps, h2, mean=mean2, rstd=rstd2)
             z = ws.get(t + "z", (M, Hd), BF16) if save else None
             a = ws.get(t + "a", (M, Hd), BF16)
-            ops.gemm(h2, w["mlp.fc1.weight"], a, bias=w["mlp.fc1.bias"], act=ops.ACT_GELU, aux_out=z)
+            ops.gemm(h2, w["mlp.fc1.weight"], a, bias=w["mlp.fc1.bias"], act=ops.ACT_GELU_DSAVE if (save and self.gelu_dsave) else ops.ACT_GELU, aux_out=z)
             x2 = ws.get(f"x.{i + 1}" if save else f"t.x{(i + 1) & 1}", (M, D), F32)
             ops.gemm(a, w["mlp.fc2.weight"], x2, bias=w["mlp.fc2.bias"], residual=x1,
                      row_scale=None if dp is None else dp[i, 1], rows_per_scale=N)
@@ -285,11 +290,12 @@ class ViTRunner:
             # ---- MLP branch
             dz = ws.get(f"bw.dz{par}", (M, Hd), BF16)
             # the fc1 bias gradient = column sums of dz comes out of this GEMM's epilogue (dz is not read again for it)
+            dact = ops.ACT_MULAUX if self.gelu_dsave else ops.ACT_DGELU        # s["z"] holds GELU'(z) in the first case, z in the second
             if self.fused_colsum:
-                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"], workspace=gcws,
+                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=dact, aux_in=s["z"], workspace=gcws,
                          colsum_out=w["g:mlp.fc1.bias"], colsum_accumulate=acc)
             else:
-                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=ops.ACT_DGELU, aux_in=s["z"])
+                ops.gemm(dxb, w["mlp.fc2.weight"], dz, trans_b=True, act=dact, aux_in=s["z"])
             # (one grouped launch of the block's four weight gradients -- ops.gemm_grouped -- is 12 % faster in isolation at 10 240
             # tokens but slower in the step: its 252 MB of operands have left the Infinity Cache by the end of the block)
 
