@@ -52,7 +52,7 @@ const char* unite_target_arch(void);
  *       q16(d) = round(65535 (d + 0.25) / 2) as an unsigned 16-bit number (the derivative lies in [-0.13, 1.13]); unq16(q) = 2 q / 65535 - 0.25.
  *       The buffer has the size and leading dimension of a bf16 one; its contents are opaque to the caller.
  *   v *= row_scale[m / rows_per_scale]             (row_scale != NULL; stochastic depth)
- *   v += residual[m,n]                             (residual != NULL; f32, or bf16 if residual_bf16 != 0; ld = ldr)
+ *   v += residual[m,n]                             (residual != NULL; f32, bf16 if residual_bf16 == 1, IEEE half if == 2; ld = ldr)
  *   v += out[m,n]                                  (accumulate != 0, f32 out only)
  *   out[m,n] = v   as f32 (out_f32 != 0) or bf16;  out_bf16_copy[m,n] = bf16(v) if given;  colsum_out (+)= column sums of out.
  * ------------------------------------------------------------------------------------ */
@@ -68,7 +68,7 @@ typedef struct unite_gemm_args {
     const void* aux_in;  int32_t ld_aux_in;     /* bf16 [M,N] */
     void* aux_out;       int32_t ld_aux_out;    /* bf16 [M,N] */
     const float* row_scale; int32_t rows_per_scale;
-    const void* residual;   int32_t ldr;        /* f32 [M,N] (bf16 [M,N] if residual_bf16 != 0, see below) */
+    const void* residual;   int32_t ldr;        /* f32 [M,N] (bf16 / half [M,N] if residual_bf16 == 1 / 2, see below) */
     void* out; int32_t ldc; int32_t out_f32; int32_t accumulate;
     void* out_bf16_copy; int32_t ld_copy;
     void* workspace; int64_t workspace_bytes;   /* optional scratch (16-byte aligned): lets short-and-wide products with a plain
@@ -95,7 +95,10 @@ typedef struct unite_gemm_args {
                                                    same bits out */
     int32_t plan_persistent;                    /* as unite_gemm_set_policy, for THIS launch only */
     float   plan_sharing;                       /* as unite_gemm_set_sharing, for THIS launch only */
-    int32_t residual_bf16;                      /* `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream) */
+    int32_t residual_bf16;                      /* 1: `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream).
+                                                   2: `residual` points at IEEE-half [M,N] AND the 16-bit `out` is written as IEEE half
+                                                   (the f16 residual stream OpenAI's CLIP runs with; out_f32, out_bf16_copy, colsum_out and
+                                                   act must be 0 / NULL then) */
     float* rowsum_a_out;                        /* optional f32 [M]: rowsum_a_out[m] (+)= sum_k op(A)[m,k] -- for a weight gradient
                                                    dW = dY^T X (trans_a = 1, A = dY stored [tokens, out]) this is the bias gradient
                                                    db = colsum(dY) (modeling_finetune.py:67,106 under autograd), taken from the A tiles
@@ -178,6 +181,10 @@ int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index,
 int unite_layernorm_fwd_bf16in(const void* x, int32_t ldx, const int32_t* row_index,
                                const float* gamma, const float* beta, float eps, const float* post_add,
                                void* y, int32_t y_f32, float* mean, float* rstd, int32_t M, int32_t D, void* stream);
+/* ... and with an IEEE-half input matrix (the teacher's f16 residual stream, unite_gemm_args.residual_bf16 == 2). */
+int unite_layernorm_fwd_f16in(const void* x, int32_t ldx, const int32_t* row_index,
+                              const float* gamma, const float* beta, float eps, const float* post_add,
+                              void* y, int32_t y_f32, float* mean, float* rstd, int32_t M, int32_t D, void* stream);
 
 /* Backward of y = LN(x)*gamma+beta.  dy is bf16 (dy_f32 == 0) or f32 [M,D].
  *   dx_out[i,:] = (dx_residual ? dx_residual[i,:] : 0) + dLN/dx
@@ -289,7 +296,7 @@ int unite_gather_rows_f32(const float* table, const int32_t* index, int32_t modu
 int unite_gather_rows_bf16(const void* table, const int32_t* index, void* out, int32_t n_rows, int32_t D, void* stream);
 
 /* CLIP token assembly + ln_pre (clip.py:148-152): patches bf16 [BT*HW, D] ->
- * x [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding), f32 (x_f32 != 0) or bf16. */
+ * x [BT*(HW+1), D] = LN([class_embedding ; patches] + positional_embedding), f32 (x_f32 == 1), bf16 (0) or IEEE half (2). */
 int unite_clip_embed_ln(const void* patches, const float* class_embedding, const float* positional_embedding,
                         const float* gamma, const float* beta, float eps, void* x, int32_t x_f32,
                         int32_t BT, int32_t HW, int32_t D, void* stream);

@@ -423,6 +423,50 @@ def test_gemm_saved_gelu_derivative(ops, M, N, K):
         ops.gemm(a.to(DEV), w2.to(DEV), out2, trans_b=True, act=ops.ACT_MULAUX)
 
 
+@pytest.mark.parametrize("M,N,K", [(330, 264, 192), (2048 + 72, 768, 768), (4096, 1024, 1024)])
+def test_gemm_f16_residual_stream(ops, M, N, K):
+    """residual_bf16 == 2: IEEE-half residual rows in, IEEE-half rows out (the frozen teacher's f16 stream: out_proj / c_proj of clip.py:60-64),
+    the sum taken in f32 and rounded once -- against fp32 torch on the same operands, tile kernels and the persistent kernel."""
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    res = (rnd(M, N, seed=4) * 3).half()
+    ref = a.float() @ w.float().t() + bias + res.float()
+    for pol in (0, 2):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+        with ops.plan(persistent=pol):
+            ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=res.to(DEV))
+        torch.testing.assert_close(out.float().cpu(), ref, atol=4e-3, rtol=1e-3)
+    with pytest.raises(Exception):          # an f16 output without the f16 residual is not a form of the kernel
+        ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV))
+    with pytest.raises(Exception):
+        ops.gemm(a.to(DEV), w.to(DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV), residual=res.to(DEV))
+
+
+def test_layernorm_and_embed_f16_rows(ops):
+    """LayerNorm reading IEEE-half rows (with and without a row gather) and the CLIP token assembly writing them."""
+    M, D = 777, 768
+    x = (rnd(M, D, seed=1, scale=3.0)).half()
+    gam, bet = rnd(D, seed=2) * 0.1 + 1, rnd(D, seed=3) * 0.1
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gam, bet, 1e-5)
+    y = torch.empty(M, D, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y)
+    torch.testing.assert_close(y.cpu(), ref, atol=1e-5, rtol=1e-5)
+    idx = torch.tensor([5, 0, 400, 776, 17], dtype=torch.int32)
+    y2 = torch.empty(5, D, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y2, row_index=idx.to(DEV))
+    torch.testing.assert_close(y2.cpu(), ref[idx.long()], atol=1e-5, rtol=1e-5)
+    g = ops.gather_rows(x.to(DEV), idx.to(DEV), torch.empty(5, D, dtype=torch.float16, device=DEV))
+    assert torch.equal(g.cpu(), x[idx.long()])
+    BT, HW = 3, 16
+    patches = bf(rnd(BT * HW, D, seed=4))
+    cls, pos = rnd(D, seed=5), rnd(HW + 1, D, seed=6)
+    x32 = torch.empty(BT * (HW + 1), D, dtype=torch.float32, device=DEV)
+    x16 = torch.empty(BT * (HW + 1), D, dtype=torch.float16, device=DEV)
+    for xo in (x32, x16):
+        ops.clip_embed_ln(patches.to(DEV), cls.to(DEV), pos.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, xo, BT, HW, D)
+    assert torch.equal(x16, x32.half())
+
+
 def test_gemm_persistent_matches_tile_kernels(ops, persistent_everywhere):
     """the teacher's c_fc shape (M = 50 432: 4 728 tiles, 18-19 per workgroup) against the same product in four row chunks that are too
     small for the persistent kernel's planner threshold... both paths accumulate k in the same order within a K-tile; allow one bf16 ulp."""

@@ -53,19 +53,26 @@ def test_state_dict_contract_tiny():
     assert sorted((k, tuple(v.shape)) for k, v in t.state_dict().items()) == sorted(teacher_shapes(TINY_T))
 
 
-def test_teacher_tiny_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("stream", ["f32", "default"])
+def test_teacher_tiny_vs_reference_golden(golden_dir, stream):
     z = _load(golden_dir, "teacher_tiny.npz")
     _, t = build_tiny()
     t.load_state_dict(fill_state_dict(teacher_shapes(TINY_T), int(z["in.seed_weights"])))
     t = t.to(DEV).eval()
+    if stream == "f32":
+        t.runtime().res16 = False          # the reference's own residual-stream type (UNITE_TEACHER_RES16=0)
+    else:
+        assert t.runtime().res16 == "f16"  # the default: IEEE-half rows, as OpenAI's CLIP runs
     feats, attn = t(torch.from_numpy(z["in.videos"]).to(DEV))
     ref_f, ref_a = torch.from_numpy(z["out.feats"]), torch.from_numpy(z["out.attn"])
     assert feats.shape == ref_f.shape and attn.shape == ref_a.shape
     assert cos_min(feats.cpu(), ref_f) >= 0.999
-    # the fixture's CLS attention rows are 4 values of 0.026 .. 0.49 (a 2 x 2 patch grid), not the 1 / 196 of the full model: the bound is
-    # 2.4 % .. 9.6 % of a value; measured on MI355X (round 4): max abs error 4.1e-3, max relative error 2.4 %, feature cosine 0.99994 -- bf16
-    # operands of the score product, nothing to spare
-    torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=2e-2)
+    # the fixture's CLS attention rows are 4 values of 0.026 .. 0.49 (a 2 x 2 patch grid), not the 1 / 196 of the full model.  With f32 rows the
+    # bound is 2.4 % .. 9.6 % of a value; measured on MI355X (round 4): max abs error 4.1e-3, max relative error 2.4 %, feature cosine 0.99994 --
+    # bf16 operands of the score product, nothing to spare.  The f16 rows of the default get the bound every other teacher test of this file
+    # states (2e-3 + 5 %): on these 16 values they land at 7.3e-3 / 6 %, while over 1536 values of 24 seeded towers their error is that of
+    # the f32 rows (1.43e-3 against 1.45e-3 rms, profiles/r04_teacher_stream_error.txt) -- any perturbation re-draws the bf16 roundings downstream.
+    torch.testing.assert_close(attn.cpu(), ref_a, atol=2e-3, rtol=2e-2 if stream == "f32" else 5e-2)
     assert cos_min(feats.cpu(), ref_f) >= 0.9998
 
 
@@ -867,7 +874,7 @@ def test_train_one_epoch_teacher_ahead_with_a_device_side_loader():
 
 
 def test_teacher_bf16_residual_stream_vs_f32_stream():
-    """UNITE_TEACHER_RES16=1 (opt-in, off by default: its attention error is outside the golden test's bound): the frozen teacher's residual
+    """UNITE_TEACHER_RES16=1 (opt-in: its attention error is outside the golden test's bound): the frozen teacher's residual
     stream, taps included, kept in bf16.  Against the f32 stream of the same weights and clips: CLS attention within 2e-2 absolute (five keys
     per frame here, probabilities ~0.2), every target row's cosine > 0.999."""
     _, t16 = build_tiny()
@@ -884,6 +891,28 @@ def test_teacher_bf16_residual_stream_vs_f32_stream():
     cos = (f16 * f32).sum(-1)
     assert float(cos.min()) > 0.999, float(cos.min())
     assert not torch.equal(a16, a32)                      # the switch does change the arithmetic
+
+
+def test_teacher_f16_residual_stream_vs_f32_stream():
+    """The default residual stream of the frozen teacher, taps included: IEEE half (what OpenAI's CLIP itself runs with).  Against the f32 stream
+    (UNITE_TEACHER_RES16=0) of the same weights and clips: CLS attention within 6e-3 absolute (measured 4.0e-3 -- the size of either arm's own
+    error against the golden vectors: a perturbation of 2^-12 is enough to re-draw the bf16 roundings of everything downstream; the bf16 stream
+    needs 2e-2), every target row's cosine > 0.9999."""
+    _, t16 = build_tiny()
+    _, t32 = build_tiny()
+    sd = fill_state_dict(teacher_shapes(TINY_T), 1)
+    t16.load_state_dict(sd)
+    t32.load_state_dict(sd)
+    t16, t32 = t16.to(DEV), t32.to(DEV)
+    t16.runtime().res16, t32.runtime().res16 = "f16", False
+    vid = make_videos(4, 2, 32, 32, seed=5).to(DEV)
+    f16, a16 = t16(vid)
+    f32, a32 = t32(vid)
+    torch.testing.assert_close(a16, a32, atol=6e-3, rtol=0)
+    cos = (f16 * f32).sum(-1)
+    assert float(cos.min()) > 0.9999, float(cos.min())
+    assert not torch.equal(a16, a32)                      # the switch does change the arithmetic
+    assert t16.runtime().ws.bufs[t16.runtime().ws.prefix + "x.a"].dtype == torch.float16
 
 
 @pytest.mark.parametrize("mask_type", ["attention", "tube"])

@@ -67,6 +67,7 @@ SIGNATURES = {
     "unite_clock_stamp": (c_i, [c_p, c_p]),
     "unite_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_fwd_bf16in": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "unite_layernorm_fwd_f16in": (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "unite_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "unite_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "unite_colsum_workspace": (c_sz, [c_i, c_i]),

@@ -125,6 +125,8 @@ class VisionTransformer(nn.Module):
 
 
 class _TeacherRuntime:
+    DEFAULT_RES16 = "f16"        # residual-stream type when UNITE_TEACHER_RES16 is unset (see __init__; tools/teacher_stream_error.py)
+
     def __init__(self, model: VisionTransformer, dev):
         if model.patch_size % 2:
             raise NotImplementedError("odd patch sizes are not built")
@@ -164,14 +166,19 @@ class _TeacherRuntime:
         self._rows_cache = {}
         self.n_streams = max(1, int(os.environ.get("UNITE_TEACHER_STREAMS", "3")))
         self.fused_qkv = os.environ.get("UNITE_TEACHER_FUSED", "1") != "0" and 192 < self.L <= 224
-        # Residual stream of the FROZEN teacher in bf16 (round 3, OPT-IN: UNITE_TEACHER_RES16=1): x, x1 and the taps are written and re-read as
-        # bf16 rows, which takes 464 MB per block off the HBM traffic of the two residual GEMMs and the two LayerNorms (2.0 -> 1.55 GB per
-        # block at B = 32).  The sums themselves stay f32 (accumulator + residual are added in f32 in the GEMM epilogue, rounded once on the
-        # store; LayerNorm statistics in f32), but each block then adds two bf16 roundings of the whole stream: measured on the tiny golden
-        # teacher the CLS attention moves by up to 1e-2 absolute (4 % relative: bf16 GEMM operands alone give 1 %), OUTSIDE the 2e-3 / 2 % bound
-        # of test_teacher_tiny_vs_reference_golden, while the L2-normalised targets keep cosine > 0.9999.  The reference's own GPU path
-        # (fp16 autocast) keeps an f32 stream, so the default stays f32; the switch exists for A/B measurements.
-        self.res16 = os.environ.get("UNITE_TEACHER_RES16", "0") != "0"
+        # Residual stream of the FROZEN teacher (UNITE_TEACHER_RES16): x, x1 and the taps are written and re-read as 16-bit rows, which takes
+        # 464 MB per block off the HBM traffic of the two residual GEMMs and the two LayerNorms (2.0 -> 1.55 GB per block at B = 32; -0.5 ms of
+        # a 19.4-ms step).  The sums themselves stay f32 (accumulator + residual are added in f32 in the GEMM epilogue, rounded once on the
+        # store; LayerNorm statistics in f32).
+        #   "f16"       (default) IEEE half rows -- the type OpenAI's CLIP keeps its own residual stream in (clip.load() on a GPU: model.half(),
+        #               LayerNorm computed in fp32), 11 significant bits.  Over 24 seeded towers against the fp32 oracle the CLS attention error is
+        #               1.43e-3 rms with it and 1.45e-3 with f32 rows, the target features' mean cosine 0.9999433 and 0.9999432
+        #               (profiles/r04_teacher_stream_error.txt): the bf16 operands of the products set the error, not this stream
+        #   "1"/"bf16"  bf16 rows (round 3): 8 significant bits; 1.74e-3 rms / 0.9999269 on the same towers, and on the tiny golden teacher the CLS
+        #               attention moves by up to 1e-2 absolute -- never the default
+        #   "0"/"f32"   f32 rows, what the reference's autocast path keeps (x + fp16 branch output -> fp32)
+        mode = os.environ.get("UNITE_TEACHER_RES16", self.DEFAULT_RES16).lower()
+        self.res16 = {"0": False, "": False, "f32": False, "1": True, "bf16": True, "f16": "f16"}[mode]
         self.min_frames_per_stream = 64
         self._side = []
         # the flat parameter buffer and its bf16 shadow were just built on the CURRENT stream: the first forward may come from another one
@@ -245,7 +252,7 @@ class _TeacherRuntime:
             conv_w = wpad
         patches = ws.get("patches", (Mp, D), BF16)
         ops.gemm(cols, conv_w, patches)
-        RES = BF16 if self.res16 else F32
+        RES = torch.float16 if self.res16 == "f16" else BF16 if self.res16 else F32
         x = ws.get("x.a", (Mt, D), RES)
         ops.clip_embed_ln(patches, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.eps, x, BT, HW, D)
         h = ws.get("h", (Mt, D), BF16)

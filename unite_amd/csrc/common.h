@@ -37,6 +37,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// IEEE half pairs (the frozen teacher's f16 residual stream): round-to-nearest-even packs, exact unpacks
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float unpack_f16_lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ __forceinline__ float unpack_f16_hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -101,11 +101,13 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 // the word once per workgroup and calls a fully-known instantiation for the combinations the training step uses: left as run-time tests inside
 // the chunk loops they were a dozen scalar branches per 8-column chunk (round 4: ~750 per workgroup in the bf16 form, profiles/r04_clock_notes.txt).
 enum : uint32_t { EF_ACT = 7u, EF_SPLIT = 8u, EF_AUXOUT = 16u, EF_SCALE = 32u, EF_RES = 64u, EF_RESBF = 128u, EF_SKIP2 = 256u, EF_OUTF32 = 512u,
-                  EF_ACCUM = 1024u, EF_NT2 = 2048u, EF_NT = 4096u, EF_COPY = 8192u, EF_CSUM = 16384u, EF_ALL = 32767u,
+                  EF_ACCUM = 1024u, EF_NT2 = 2048u, EF_NT = 4096u, EF_COPY = 8192u, EF_CSUM = 16384u,
+                  EF_F16 = 65536u,           // the 16-bit residual and a 16-bit output are IEEE half (residual_bf16 == 2), not bf16
+                  EF_ALL = 32767u | 65536u,
                   EF_RESPRE = 32768u };      // (caller-only bit) the f32 residual chunk is passed in (r0 | r1): the caller loaded it ahead of the pass
 __device__ __forceinline__ uint32_t epilogue_features(const Params& p, const unite_gemm_args& g, bool csum) {
     return (uint32_t)g.act | (p.splitk > 1 ? EF_SPLIT : 0u) | (g.aux_out ? EF_AUXOUT : 0u) | (g.row_scale ? EF_SCALE : 0u) | (g.residual ? EF_RES : 0u) |
-           (g.residual_bf16 ? EF_RESBF : 0u) | (p.debug_skip == 2 ? EF_SKIP2 : 0u) | (g.out_f32 ? EF_OUTF32 : 0u) | (g.accumulate ? EF_ACCUM : 0u) |
+           (g.residual_bf16 ? EF_RESBF : 0u) | (g.residual_bf16 == 2 ? EF_F16 : 0u) | (p.debug_skip == 2 ? EF_SKIP2 : 0u) | (g.out_f32 ? EF_OUTF32 : 0u) | (g.accumulate ? EF_ACCUM : 0u) |
            (p.nt_store == 2 ? EF_NT2 : 0u) | (p.nt_store ? EF_NT : 0u) | (g.out_bf16_copy ? EF_COPY : 0u) | (csum ? EF_CSUM : 0u);
 }
 #define UNITE_EF(bit, runtime) ((KNOWN & (bit)) ? ((VALUE & (bit)) != 0u) : (runtime))
@@ -169,10 +171,18 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
     if (UNITE_EF(EF_RES, g.residual != nullptr)) {
         if (UNITE_EF(EF_RESBF, g.residual_bf16 != 0)) {
             const u32x4 r = *(const u32x4*)((const uint16_t*)g.residual + (size_t)gm * g.ldr + gn);
+            if (UNITE_EF(EF_F16, g.residual_bf16 == 2)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] += __uint_as_float(r[e] << 16);
-                v[2 * e + 1] += __uint_as_float(r[e] & 0xFFFF0000u);
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += unpack_f16_lo(r[e]);
+                    v[2 * e + 1] += unpack_f16_hi(r[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __uint_as_float(r[e] << 16);
+                    v[2 * e + 1] += __uint_as_float(r[e] & 0xFFFF0000u);
+                }
             }
         } else if ((KNOWN & EF_RESPRE) && (VALUE & EF_RESPRE)) {
 #pragma unroll
@@ -208,7 +218,9 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
             *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
         }
     } else {
-        u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        u32x4 o;
+        if (UNITE_EF(EF_F16, g.residual_bf16 == 2)) o = (u32x4){pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7])};
+        else o = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         if (UNITE_EF(EF_NT2, p.nt_store == 2)) {
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, 0, 0x7FFFFFF0, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(o, ro, (uint32_t)(((size_t)gm * g.ldc + gn) * 2), 0, 16);
@@ -908,6 +920,8 @@ __global__ __launch_bounds__(HALF * 4, 2) void gemm_deep_kernel(const Params p) 
 #define UNITE_HOT(v) if (fw == (uint32_t)(v)) chunks(KA{}, std::integral_constant<uint32_t, (uint32_t)(v)>{}, h, nullptr); else
         if (fw == (EF_OUTF32 | EF_RES)) chunks4(std::integral_constant<uint32_t, EF_OUTF32 | EF_RES>{}, h);              // teacher out_proj / c_proj
         else if (fw == (EF_OUTF32 | EF_RES | EF_SCALE)) chunks4(std::integral_constant<uint32_t, EF_OUTF32 | EF_RES | EF_SCALE>{}, h);   // student proj / fc2
+        else if (fw == (EF_RES | EF_RESBF | EF_F16 | EF_NT2 | EF_NT)) chunks4(std::integral_constant<uint32_t, EF_RES | EF_RESBF | EF_F16 | EF_NT2 | EF_NT>{}, h);   // teacher out_proj / c_proj, f16 stream
+        else if (fw == (EF_RES | EF_RESBF | EF_F16)) chunks4(std::integral_constant<uint32_t, EF_RES | EF_RESBF | EF_F16>{}, h);
         else
         UNITE_HOT(UNITE_ACT_DGELU)                                           // fc2 input gradient x GELU'(z), bf16
         UNITE_HOT(UNITE_ACT_DGELU | EF_NT2 | EF_NT)
@@ -1437,6 +1451,9 @@ int check_problem(const unite_gemm_args& g, int64_t& a_bytes, int64_t& b_bytes) 
     if (g.aux_out && (g.ld_aux_out & 7)) return UNITE_EINVAL;
     if (g.row_scale && g.rows_per_scale <= 0) return UNITE_EINVAL;
     if (g.residual && ((g.ldr & (g.residual_bf16 ? 7 : 3)) || !aligned16(g.residual))) return UNITE_EINVAL;
+    if (g.residual_bf16 < 0 || g.residual_bf16 > 2) return UNITE_EINVAL;
+    // the f16 stream: f16 residual rows in, f16 rows out -- nothing else of the epilogue knows that type
+    if (g.residual_bf16 == 2 && (!g.residual || g.out_f32 || g.out_bf16_copy || g.colsum_out || g.act != UNITE_ACT_NONE)) return UNITE_EINVAL;
     if ((g.plan_flags & 1) && (g.plan_persistent < 0 || g.plan_persistent > 2)) return UNITE_EINVAL;
     if (g.out_bf16_copy && (g.ld_copy & 7)) return UNITE_EINVAL;
     const int64_t a_rows = g.trans_a ? g.K : g.M, a_cols = g.trans_a ? g.M : g.K;

@@ -40,7 +40,7 @@ struct PPParams {
     int32_t nbm, nbn, ntiles, nk;
     uint32_t rps_magic;                       // ceil(2^32 / rows_per_scale): row / rows_per_scale = umulhi(row, magic), exact for row < 2^20, divisor in [2, 2^12]
     int32_t wt_store;                         // large bf16 outputs are written through (sc1) so that they do not evict the operand panels from the L2
-    int32_t res16;                            // bf16 output + bf16 residual (unite_gemm_args.residual_bf16): the residual rows travel in the aux_in slot
+    int32_t res16;                            // 1: bf16 output + bf16 residual, 2: the same in IEEE half (unite_gemm_args.residual_bf16): the residual rows travel in the aux_in slot
     int32_t ld_aux;                           // row stride of whatever the aux_in slot reads (saved pre-activations or the bf16 residual)
 };
 
@@ -277,6 +277,13 @@ __device__ __forceinline__ EpiOut epi_math(const PPParams& p, EpiRegs& e, const 
                 v[2 * r] *= gelu_erf_grad(__uint_as_float(z[r] << 16));
                 v[2 * r + 1] *= gelu_erf_grad(__uint_as_float(z[r] & 0xFFFF0000u));
             }
+        } else if (p.res16 == 2) {            // the f16 stream: half rows in, half rows out
+            const u32x4 z = __builtin_bit_cast(u32x4, e.r0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[2 * r] += unpack_f16_lo(z[r]);
+                v[2 * r + 1] += unpack_f16_hi(z[r]);
+            }
         } else if (p.res16) {
             const u32x4 z = __builtin_bit_cast(u32x4, e.r0);
 #pragma unroll
@@ -285,7 +292,8 @@ __device__ __forceinline__ EpiOut epi_math(const PPParams& p, EpiRegs& e, const 
                 v[2 * r + 1] += __uint_as_float(z[r] & 0xFFFF0000u);
             }
         }
-        out.o0 = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        if (p.res16 == 2) out.o0 = (u32x4){pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7])};
+        else out.o0 = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
     }
     return out;
 }
@@ -591,7 +599,7 @@ int unite_gemm_pp_launch(const unite_gemm_args& g, int64_t a_bytes, int64_t b_by
     p.b_bytes = (uint32_t)b_bytes;
     const int esz = g.out_f32 ? 4 : 2;
     p.out_bytes = (uint32_t)(((int64_t)(g.M - 1) * g.ldc + g.N) * esz);
-    p.res16 = (!g.out_f32 && g.residual && g.residual_bf16) ? 1 : 0;
+    p.res16 = (!g.out_f32 && g.residual && g.residual_bf16) ? g.residual_bf16 : 0;      // 1 bf16 rows, 2 f16 rows
     p.res_bytes = (g.residual && !p.res16) ? (uint32_t)(((int64_t)(g.M - 1) * g.ldr + g.N) * 4) : 0u;
     p.bias_bytes = g.bias ? (uint32_t)g.N * 4u : 0u;
     p.ld_aux = p.res16 ? g.ldr : g.ld_aux_in;

@@ -39,6 +39,18 @@ __device__ __forceinline__ void load_row_bf16(const uint16_t* row, int D, int la
 }
 
 template <int NV>
+__device__ __forceinline__ void load_row_f16(const uint16_t* row, int D, int lane, f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const u32x2 w = *(const u32x2*)(row + c);
+            v[i] = (f32x4){unpack_f16_lo(w[0]), unpack_f16_hi(w[0]), unpack_f16_lo(w[1]), unpack_f16_hi(w[1])};
+        } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int NV>
 __device__ __forceinline__ void row_stats(const f32x4 (&v)[NV], int D, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
@@ -57,12 +69,13 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NV], int D, int lane,
 }
 
 __device__ __forceinline__ void store4(void* y, int y_f32, size_t off, f32x4 o) {
-    if (y_f32) *(f32x4*)((float*)y + off) = o;
+    if (y_f32 == 1) *(f32x4*)((float*)y + off) = o;
+    else if (y_f32 == 2) *(u32x2*)((uint16_t*)y + off) = (u32x2){pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3])};      // IEEE half (teacher stream)
     else *(u32x2*)((uint16_t*)y + off) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NV, bool XBF>
+template <int NV, int XK>      // XK: the input rows are 0 f32, 1 bf16, 2 IEEE half
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x, int ldx, const int32_t* __restrict__ row_index,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ post_add, void* __restrict__ y, int y_f32,
@@ -72,7 +85,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
     if (row >= M) return;
     const int src = row_index ? row_index[row] : row;
     f32x4 v[NV];
-    if (XBF) load_row_bf16<NV>((const uint16_t*)x + (size_t)src * ldx, D, lane, v);
+    if (XK == 1) load_row_bf16<NV>((const uint16_t*)x + (size_t)src * ldx, D, lane, v);
+    else if (XK == 2) load_row_f16<NV>((const uint16_t*)x + (size_t)src * ldx, D, lane, v);
     else load_row<NV>((const float*)x + (size_t)src * ldx, D, lane, v);
     float mean, rstd;
     row_stats<NV>(v, D, lane, eps, mean, rstd);
@@ -481,7 +495,7 @@ extern "C" int unite_layernorm_fwd(const float* x, int32_t ldx, const int32_t* r
                                    int32_t M, int32_t D, void* stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, false>), dim3((M + 3) / 4), dim3(256), 0, s, (const void*)x, ldx, row_index,
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 0>), dim3((M + 3) / 4), dim3(256), 0, s, (const void*)x, ldx, row_index,
                                       gamma, beta, eps, post_add, y, y_f32, mean, rstd, M, D));
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;
@@ -492,7 +506,18 @@ extern "C" int unite_layernorm_fwd_bf16in(const void* x, int32_t ldx, const int3
                                           int32_t M, int32_t D, void* stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3) || (((uintptr_t)x) & 7)) return UNITE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, true>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 1>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
+                                      beta, eps, post_add, y, y_f32, mean, rstd, M, D));
+    UNITE_LAUNCH_CHECK();
+    return UNITE_OK;
+}
+
+extern "C" int unite_layernorm_fwd_f16in(const void* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                                         float eps, const float* post_add, void* y, int32_t y_f32, float* mean, float* rstd,
+                                         int32_t M, int32_t D, void* stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || !dim_ok(D) || (ldx & 3) || (((uintptr_t)x) & 7)) return UNITE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 2>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, row_index, gamma,
                                       beta, eps, post_add, y, y_f32, mean, rstd, M, D));
     UNITE_LAUNCH_CHECK();
     return UNITE_OK;

@@ -15,6 +15,7 @@ from . import _lib
 ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_DGELU, ACT_GELU_DSAVE, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
 F32 = torch.float32
+F16 = torch.float16
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -183,12 +184,14 @@ def _gemm_args(a, b, out, trans_a, trans_b, bias, act, aux_in, aux_out, row_scal
     g.aux_in, g.ld_aux_in = _ptr(aux_in), (aux_in.stride(0) if aux_in is not None else 0)
     g.aux_out, g.ld_aux_out = _ptr(aux_out), (aux_out.stride(0) if aux_out is not None else 0)
     g.row_scale, g.rows_per_scale = _ptr(row_scale), rows_per_scale
-    if residual is not None and residual.dtype not in (F32, BF16):
-        raise TypeError("residual must be f32 or bf16")
+    if residual is not None and residual.dtype not in (F32, BF16, F16):
+        raise TypeError("residual must be f32, bf16 or f16")
     g.residual, g.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
-    g.residual_bf16 = int(residual is not None and residual.dtype == BF16)
-    if out.dtype not in (BF16, F32):
-        raise TypeError("out must be bf16 or f32")
+    g.residual_bf16 = 0 if residual is None else 2 if residual.dtype == F16 else int(residual.dtype == BF16)
+    if (out.dtype == F16) != (g.residual_bf16 == 2):
+        raise ValueError("an f16 output goes with an f16 residual (the teacher's f16 residual stream) and nothing else")
+    if out.dtype not in (BF16, F32, F16):
+        raise TypeError("out must be bf16, f32 or (with an f16 residual) f16")
     g.out, g.ldc, g.out_f32, g.accumulate = _ptr(out), out.stride(0), int(out.dtype == F32), int(accumulate)
     g.out_bf16_copy, g.ld_copy = _ptr(out_bf16_copy), (out_bf16_copy.stride(0) if out_bf16_copy is not None else 0)
     if workspace is not None:
@@ -211,6 +214,11 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, eps: float, y: torch.Tensor, *, 
                   mean=None, rstd=None) -> torch.Tensor:
     lib = _lib.load()
     M, D = y.shape
+    if x.dtype == F16:           # the teacher's f16 residual stream
+        _lib.check(lib.unite_layernorm_fwd_f16in(_ptr(x), x.stride(0), _ptr(row_index), _ptr(gamma), _ptr(beta), eps, _ptr(post_add),
+                                                 _ptr(y), int(y.dtype == F32), _ptr(mean), _ptr(rstd), M, D, _stream()),
+                   "unite_layernorm_fwd_f16in")
+        return y
     if x.dtype == BF16:          # the teacher's bf16 residual stream
         _req(x, BF16, "x")
         _lib.check(lib.unite_layernorm_fwd_bf16in(_ptr(x), x.stride(0), _ptr(row_index), _ptr(gamma), _ptr(beta), eps, _ptr(post_add),
@@ -380,8 +388,8 @@ def resize_bicubic(video, out):
 
 def gather_rows(table, index, out, modulo: int = 0):
     lib = _lib.load()
-    if table.dtype == BF16:
-        _req(out, BF16, "out")
+    if table.dtype in (BF16, F16):          # a copy of 16-bit rows either way
+        _req(out, table.dtype, "out")
         assert modulo == 0 and index is not None
         _lib.check(lib.unite_gather_rows_bf16(_ptr(table), _ptr(index), _ptr(out), out.shape[0], out.shape[1], _stream()), "unite_gather_rows_bf16")
         return out
@@ -392,7 +400,7 @@ def gather_rows(table, index, out, modulo: int = 0):
 
 def clip_embed_ln(patches, cls, pos, gamma, beta, eps: float, x, BT: int, HW: int, D: int):
     lib = _lib.load()
-    _lib.check(lib.unite_clip_embed_ln(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), eps, _ptr(x), int(x.dtype == F32), BT, HW, D,
+    _lib.check(lib.unite_clip_embed_ln(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), eps, _ptr(x), 1 if x.dtype == F32 else 2 if x.dtype == F16 else 0, BT, HW, D,
                                        _stream()),
                "unite_clip_embed_ln")
     return x
