@@ -2,7 +2,7 @@
 Under a sustained MFMA load the chip lowers its clock until it fits its power limit, so the time per launch of a long loop measures the
 ENERGY a launch costs (time = energy / power limit), where a short interleaved burst (tools/gemm_sched_ab.py) measures its cycles.  The
 training step is a sustained load (profiles/r04_clock_notes.txt), so this is the figure that predicts it.
-Usage: python tools/sustained.py [seconds] "name:M,N,K[,f32][,bias][,qgelu][,gelu (+ saved pre-activation)][,dgelu][,dsave (GELU + saved derivative)][,mulaux][,res][,nt][,tn][,vendor][,s0][,e0|,e1][,pp]" ...   (UNITE_GEMM_DEBUG_SKIP etc. apply)"""
+Usage: python tools/sustained.py [seconds] "name:M,N,K[,f32][,bias][,qgelu][,gelu (+ saved pre-activation)][,dgelu][,dsave (GELU + saved derivative)][,mulaux][,res][,res16 (f16 residual rows in, f16 rows out)][,nt][,tn][,vendor][,s0][,e0|,e1][,pp]" ...   (UNITE_GEMM_DEBUG_SKIP etc. apply)"""
 import os
 import sys
 
@@ -31,7 +31,9 @@ def main():
         w = torch.randn((K, N) if (tn or nt) else (N, K), device=dev).bfloat16()
         out = torch.empty(M, N, dtype=torch.float32 if (tn or "f32" in o) else torch.bfloat16, device=dev)
         bias = torch.randn(N, device=dev) if "bias" in o else None
-        res = torch.randn(M, N, device=dev) if "res" in o else None
+        res = torch.randn(M, N, device=dev) if "res" in o else torch.randn(M, N, device=dev).half() if "res16" in o else None
+        if "res16" in o:
+            out = torch.empty(M, N, dtype=torch.float16, device=dev)
         act = (ops.ACT_QUICKGELU if "qgelu" in o else ops.ACT_GELU if "gelu" in o else ops.ACT_DGELU if "dgelu" in o else
                ops.ACT_GELU_DSAVE if "dsave" in o else ops.ACT_MULAUX if "mulaux" in o else ops.ACT_NONE)
         aux_out = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if ("gelu" in o or "dsave" in o) else None
