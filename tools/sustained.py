@@ -2,7 +2,7 @@
 Under a sustained MFMA load the chip lowers its clock until it fits its power limit, so the time per launch of a long loop measures the
 ENERGY a launch costs (time = energy / power limit), where a short interleaved burst (tools/gemm_sched_ab.py) measures its cycles.  The
 training step is a sustained load (profiles/r04_clock_notes.txt), so this is the figure that predicts it.
-Usage: python tools/sustained.py [seconds] "name:M,N,K[,f32][,bias][,qgelu][,gelu (+ saved pre-activation)][,dgelu][,dsave (GELU + saved derivative)][,mulaux][,res][,res16 (f16 residual rows in, f16 rows out)][,nt][,tn][,vendor][,s0][,e0|,e1][,pp]" ...   (UNITE_GEMM_DEBUG_SKIP etc. apply)"""
+Usage: python tools/sustained.py [seconds] "name:M,N,K[,f32][,bias][,qgelu][,gelu (+ saved pre-activation)][,dgelu][,dsave (GELU + saved derivative)][,mulaux][,res][,res16 (f16 residual rows in, f16 rows out)][,nt][,tn][,vendor][,s0][,e0|,e1][,pp][,w8|,w9 (planner sharing weight 0.8 / 0.9, as in the step)]" ...   (UNITE_GEMM_DEBUG_SKIP etc. apply)"""
 import os
 import sys
 
@@ -45,9 +45,10 @@ def main():
             sched = 0 if "s0" in o else 1
             pp = 1 if "pp" in o else 0
             epi = 1 if "e1" in o else 0 if "e0" in o else None
+            share = 0.8 if "w8" in o else 0.9 if "w9" in o else None
 
             def fn():
-                with ops.plan(persistent=2 if pp else 0, sched=sched, epi=epi):
+                with ops.plan(persistent=2 if pp else 0, sched=sched, epi=epi, sharing=share):
                     ops.gemm(a, w, out, trans_a=tn, trans_b=tn or nt, bias=bias, act=act, residual=res, workspace=ws, aux_out=aux_out, aux_in=aux_in)
         c, us = probe_while(fn, seconds)
         print(f"{name or rest:34s} {rest:40s} {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF/s  clock {c['mean']:6.0f} MHz", flush=True)

@@ -1578,8 +1578,15 @@ extern "C" int unite_gemm_bf16(const unite_gemm_args* args, void* stream) {
         static const char* band_s = getenv("UNITE_GEMM_PP_BAND");
         static const int band_lo = band_s ? atoi(band_s) : 256, band_hi = (band_s && strchr(band_s, ',')) ? atoi(strchr(band_s, ',') + 1) : 1000;
         const int pp_tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-        const bool measured = !g.trans_b && (pp_tiles <= band_lo || pp_tiles >= band_hi) &&
-                              (g.out_f32 || (g.act != UNITE_ACT_QUICKGELU && (int64_t)g.M * g.N <= (int64_t)32 << 20));
+        bool measured = !g.trans_b && (pp_tiles <= band_lo || pp_tiles >= band_hi) &&
+                        (g.out_f32 || (g.act != UNITE_ACT_QUICKGELU && (int64_t)g.M * g.N <= (int64_t)32 << 20));
+        // Round 4, in-step A/B (profiles/r04_clock_notes.txt section 20): the student's fc2 at B = 32 (10 240 x 768, K = 3072: 240 persistent tiles, every
+        // CU held for the whole launch) is better off on the tile kernels, which at the step's sharing weight take 120 CUs and leave the rest to the
+        // teacher's stream: -0.10 ms per step (3 of 3 rounds); ViT-L's fc2 (5120 x 1024, K = 4096: 160 tiles) the other way round (+0.2 ms of 32.6).
+        // Tried in the same call and left alone: the teacher's QuickGELU c_fc per frame range on the persistent kernel (equal), the qkv input
+        // gradient on it (+0.2 ms).  UNITE_GEMM_PP_FC2=0 switches the rule off.
+        static const bool fc2_rule = !getenv("UNITE_GEMM_PP_FC2") || atoi(getenv("UNITE_GEMM_PP_FC2")) != 0;
+        if (fc2_rule && g.out_f32 && g.K >= 2048 && pp_tiles > 192 && pp_tiles <= band_lo) measured = false;
         if (pp && (pp == 2 || measured) && !force_k && !g.rowsum_a_out && ((g.M + 255) / 256) * ((g.N + 127) / 128) >= pp_min && unite_gemm_pp_supported(g)) {
             hipStream_t s = (hipStream_t)stream;
             const bool prof = g_prof.on && g_prof.used < g_prof.ev.size();
