@@ -498,3 +498,34 @@ def test_stage3_step_vs_reference_golden(strategy, golden_dir):
             assert g is None or float(g.abs().max()) == 0.0
         elif pre + "g." + kk in z.files:
             assert rel_l2(g.cpu(), torch.from_numpy(z[pre + "g." + kk])) <= 5e-2, kk
+
+
+def test_setup_clip_text_side_feeds_clip_infer(tmp_path):
+    """utils.setup_clip (src/utils.py:44-53) with the text side built here: a seeded CLIP text transformer (OpenAI's key names, output dim 512) and a
+    synthetic BPE merge table on disk -> class text features of the 8 reference class names (src/utils.py:70-82) -> utils.clip_infer on the HIP image
+    tower (src/utils.py:55-68): a probability row per clip, equal to the torch restatement of the similarity on the tower's own features.
+    (PARITY UNPINNED for the text side: tests/test_clip_text.py.)"""
+    import gzip
+    from types import SimpleNamespace
+    from tests.test_clip_text import MERGES, _seeded_text_weights
+    from unite_amd import clip_text, utils
+    vocab = tmp_path / "merges.txt.gz"
+    with gzip.open(vocab, "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic\n" + "\n".join(a + " " + b for a, b in MERGES) + "\n")
+    sd = _seeded_text_weights(width=128, layers=2, vocab=512 + len(MERGES) + 2, context=77, out=512, seed=3)
+    torch.save(sd, tmp_path / "text.pt")
+    args = SimpleNamespace(nb_classes=8, clip_text_weights=str(tmp_path / "text.pt"), clip_bpe_vocab=str(vocab), clip_text_features="",
+                           clip_teacher_weights="")
+    torch.manual_seed(11)
+    model, text = utils.setup_clip(args, DEV)
+    assert text.shape == (8, 512) and text.dtype == torch.float32 and text.is_cuda
+    want = clip_text.class_text_features(utils.get_class_names(args), clip_text.BpeTokenizer(str(vocab)), clip_text.TextTower(sd))
+    torch.testing.assert_close(text.cpu(), want, rtol=1e-3, atol=1e-4)
+    videos = torch.randn(2, 3, 4, 224, 224, generator=torch.Generator().manual_seed(5)).to(DEV)
+    probs = utils.clip_infer(model, videos, text.clone())
+    assert probs.shape == (2, 8)
+    torch.testing.assert_close(probs.sum(-1).cpu(), torch.ones(2), rtol=1e-4, atol=1e-4)
+    img = model.encode_image(videos).float()                    # L2-normalised frame embeddings of the same tower
+    t = text / text.norm(dim=-1, keepdim=True)
+    ref = (100 * img @ t.T).softmax(-1).view(2, 4, 8).mean(1)
+    torch.testing.assert_close(probs, ref, rtol=2e-3, atol=2e-4)

@@ -5,7 +5,7 @@ written over everything (run_stage1.py:231-270).  The flag tables are interface 
 read from the reference's source (oracle/make_golden_cli.py -> tests/golden/cli_flags.json) and checks the precedence rules.
 
 Extra flags of this build (absent from the reference, all optional): ``--synthetic`` (seeded random clips instead of a dataset: the
-reference has no offline data path), ``--synthetic_steps``, ``--dist_backend``, ``--clip_teacher_weights``, ``--clip_text_features`` (stage 3).
+reference has no offline data path), ``--synthetic_steps``, ``--dist_backend``, ``--clip_teacher_weights``, ``--clip_text_features`` / ``--clip_text_weights`` + ``--clip_bpe_vocab`` (stage 3).
 """
 from __future__ import annotations
 
@@ -241,6 +241,8 @@ EXTRA = [
     A("--dist_backend", default="nccl", type=str),
     A("--clip_teacher_weights", default="", type=str),
     A("--clip_text_features", default="", type=str),      # stage 3: class text embeddings (nb_classes, C) for the zero-shot CLIP side (.pt / .npy)
+    A("--clip_text_weights", default="", type=str),       # ... or OpenAI CLIP's text-side weights (state dict) and
+    A("--clip_bpe_vocab", default="", type=str),          # its BPE merge table (bpe_simple_vocab_16e6.txt.gz): unite_amd/clip_text.py
 ]
 
 

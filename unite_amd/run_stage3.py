@@ -68,18 +68,12 @@ def zero_shot_probs_fn(args, device, seed):
     utils.setup_clip + utils.clip_infer), or None for the strategies that do not use CLIP."""
     if args.selection_strategy not in ('clip_matchORconf', 'clip_only'):
         return None
-    weights = getattr(args, "clip_teacher_weights", "") or os.environ.get("UNITE_CLIP_PATH", "")
-    tower = clip.clip_b16(pretrained=bool(weights), return_attn=False, clip_return_layers=[11]).to(device)      # utils.setup_clip loads "ViT-B/16"
-    path = getattr(args, "clip_text_features", "")
-    if path:
-        import numpy as np
-        text = torch.from_numpy(np.load(path)) if path.endswith(".npy") else torch.load(path, map_location="cpu", weights_only=True)
-        text = text.float().to(device)
-    elif args.synthetic:
+    if args.synthetic and not (getattr(args, "clip_text_features", "") or getattr(args, "clip_text_weights", "")):
+        weights = getattr(args, "clip_teacher_weights", "") or os.environ.get("UNITE_CLIP_PATH", "")
+        tower = clip.clip_b16(pretrained=bool(weights), return_attn=False, clip_return_layers=[11]).to(device)      # utils.setup_clip loads "ViT-B/16"
         text = torch.randn(args.nb_classes, tower.output_dim, generator=torch.Generator().manual_seed(seed + 99)).to(device)
     else:
-        raise NotImplementedError("selection_strategy %r needs class text embeddings: pass --clip_text_features (the OpenAI tokenizer / text "
-                                  "tower of utils.setup_clip is outside this build)" % args.selection_strategy)
+        tower, text = utils.setup_clip(args, device)          # run_stage3.py:376-377
     if text.shape != (args.nb_classes, tower.output_dim):
         raise ValueError(f"text features must be ({args.nb_classes}, {tower.output_dim}), got {tuple(text.shape)}")
     return partial(lambda videos, m, t: utils.clip_infer(m, videos, t), m=tower, t=text)

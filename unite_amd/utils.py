@@ -121,7 +121,7 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 def clip_infer(model, videos, text_features):
     """reference utils.clip_infer: per-frame image embeddings (here: unite_amd.clip.VisionTransformer.encode_image, i.e. the frozen
     CLIP image tower on the HIP kernels), cosine similarity x 100 against the class text embeddings, soft-max, mean over the frames.
-    ``text_features`` (n_classes, C) come from the caller: OpenAI's tokenizer / text tower are not part of this build."""
+    ``text_features`` (n_classes, C): what setup_clip returned (unite_amd.clip_text, or a file of embeddings)."""
     B, T = videos.shape[0], videos.shape[2]
     img = model.encode_image(videos)
     text = text_features.float()
@@ -437,9 +437,25 @@ def get_class_names(args):
 
 
 def setup_clip(args, device):
-    raise NotImplementedError("utils.setup_clip loads OpenAI CLIP ('clip.load') and tokenises class prompts: the text tower and its "
-                              "weights are outside the built path.  Build the image side with unite_amd.clip.clip_b16(return_cls=...) "
-                              "weights and pass text features to utils.clip_infer(model, videos, text_features).")
+    """(image tower, class text features) for the zero-shot side of stage 3 -- src/utils.py:44-53, where ``clip.load("ViT-B/16")`` gives both and
+    ``clip.tokenize`` / ``encode_text`` make the features.  Here the image tower is unite_amd.clip.clip_b16 on the HIP kernels
+    (``args.clip_teacher_weights`` / UNITE_CLIP_PATH for its weights) and the text side is unite_amd.clip_text (OpenAI CLIP's tokenizer and text
+    transformer restated; needs ``args.clip_text_weights``: a state dict with OpenAI's text-side keys, and ``args.clip_bpe_vocab``: that package's
+    bpe_simple_vocab_16e6.txt.gz -- neither exists offline).  ``args.clip_text_features`` (a (nb_classes, C) .pt / .npy) short-cuts the text side."""
+    from . import clip as _clip
+    from . import clip_text
+    feats = getattr(args, "clip_text_features", "")
+    tw, vocab = getattr(args, "clip_text_weights", ""), getattr(args, "clip_bpe_vocab", "")
+    if not feats and not (tw and vocab):
+        raise NotImplementedError("utils.setup_clip needs the class text embeddings: pass --clip_text_features, or --clip_text_weights (OpenAI CLIP "
+                                  "state dict with its text-side keys) together with --clip_bpe_vocab (bpe_simple_vocab_16e6.txt.gz)")
+    weights = getattr(args, "clip_teacher_weights", "") or os.environ.get("UNITE_CLIP_PATH", "")
+    model = _clip.clip_b16(pretrained=bool(weights), return_attn=False, clip_return_layers=[11]).to(device)
+    if feats:
+        text = torch.from_numpy(np.load(feats)) if feats.endswith(".npy") else torch.load(feats, map_location="cpu", weights_only=True)
+    else:
+        text = clip_text.class_text_features(get_class_names(args), clip_text.BpeTokenizer(vocab), clip_text.load_text_tower(tw, device))
+    return model, text.float().to(device)
 
 
 def create_ds_config(args):
