@@ -103,8 +103,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int row0, int 
 enum : uint32_t { EF_ACT = 7u, EF_SPLIT = 8u, EF_AUXOUT = 16u, EF_SCALE = 32u, EF_RES = 64u, EF_RESBF = 128u, EF_SKIP2 = 256u, EF_OUTF32 = 512u,
                   EF_ACCUM = 1024u, EF_NT2 = 2048u, EF_NT = 4096u, EF_COPY = 8192u, EF_CSUM = 16384u,
                   EF_F16 = 65536u,           // the 16-bit residual and a 16-bit output are IEEE half (residual_bf16 == 2), not bf16
-                  EF_ALL = 32767u | 65536u,
-                  EF_RESPRE = 32768u };      // (caller-only bit) the f32 residual chunk is passed in (r0 | r1): the caller loaded it ahead of the pass
+                  EF_ALL = 32767u | 65536u };
 __device__ __forceinline__ uint32_t epilogue_features(const Params& p, const unite_gemm_args& g, bool csum) {
     return (uint32_t)g.act | (p.splitk > 1 ? EF_SPLIT : 0u) | (g.aux_out ? EF_AUXOUT : 0u) | (g.row_scale ? EF_SCALE : 0u) | (g.residual ? EF_RES : 0u) |
            (g.residual_bf16 ? EF_RESBF : 0u) | (g.residual_bf16 == 2 ? EF_F16 : 0u) | (p.debug_skip == 2 ? EF_SKIP2 : 0u) | (g.out_f32 ? EF_OUTF32 : 0u) | (g.accumulate ? EF_ACCUM : 0u) |
@@ -118,8 +117,7 @@ __device__ __forceinline__ uint32_t epilogue_features(const Params& p, const uni
 // load issued between the stores of two passes could only be waited for together with every store before it.
 template <uint32_t KNOWN = 0u, uint32_t VALUE = 0u>
 __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm_args& g, int slice, int gm, int gn, f32x4 v0, f32x4 v1,
-                                               f32x4 b0, f32x4 b1, float* csum = nullptr, f32x4 pr0 = (f32x4){0.f, 0.f, 0.f, 0.f},
-                                               f32x4 pr1 = (f32x4){0.f, 0.f, 0.f, 0.f}) {
+                                               f32x4 b0, f32x4 b1, float* csum = nullptr) {
     if (UNITE_EF(EF_SPLIT, p.splitk > 1)) {      // raw partial product -> slab, write-through (sc1): the tile's last slice to finish reads it in this launch
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slab + (size_t)slice * g.M * g.N), 0, 0x7FFFFFF0, 0x00020000);
         const uint32_t off = (uint32_t)(((size_t)gm * g.N + gn) * 4);
@@ -184,9 +182,6 @@ __device__ __forceinline__ void epilogue_chunk(const Params& p, const unite_gemm
                     v[2 * e + 1] += __uint_as_float(r[e] & 0xFFFF0000u);
                 }
             }
-        } else if ((KNOWN & EF_RESPRE) && (VALUE & EF_RESPRE)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += pr0[e]; v[4 + e] += pr1[e]; }
         } else {
             const float* rp = (const float*)g.residual + (size_t)gm * g.ldr + gn;
             const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
