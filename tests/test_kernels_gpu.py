@@ -436,6 +436,14 @@ def test_gemm_f16_residual_stream(ops, M, N, K):
         with ops.plan(persistent=pol):
             ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=res.to(DEV))
         torch.testing.assert_close(out.float().cpu(), ref, atol=4e-3, rtol=1e-3)
+    # column windows of wider buffers (ldr, ldc > N) and a row range, as the teacher's frame ranges address their slices
+    wide_r = torch.full((M, N + 16), float("nan"), dtype=torch.float16, device=DEV)
+    wide_o = torch.full((M, N + 24), float("nan"), dtype=torch.float16, device=DEV)
+    wide_r[:, 8:8 + N] = res.to(DEV)
+    r0 = 64 if M > 128 else 0
+    ops.gemm(a.to(DEV)[r0:], w.to(DEV), wide_o[r0:, 16:16 + N], bias=bias.to(DEV), residual=wide_r[r0:, 8:8 + N])
+    torch.testing.assert_close(wide_o[r0:, 16:16 + N].float().cpu(), ref[r0:], atol=4e-3, rtol=1e-3)
+    assert torch.isnan(wide_o[:, :16]).all() and torch.isnan(wide_o[:, 16 + N:]).all() and torch.isnan(wide_o[:r0]).all()
     with pytest.raises(Exception):          # an f16 output without the f16 residual is not a form of the kernel
         ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV))
     with pytest.raises(Exception):
@@ -455,6 +463,10 @@ def test_layernorm_and_embed_f16_rows(ops):
     y2 = torch.empty(5, D, dtype=torch.float32, device=DEV)
     ops.layernorm_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, y2, row_index=idx.to(DEV))
     torch.testing.assert_close(y2.cpu(), ref[idx.long()], atol=1e-5, rtol=1e-5)
+    xw = torch.full((M, D + 8), float("nan"), dtype=torch.float16, device=DEV)          # ldx > D
+    xw[:, :D] = x.to(DEV)
+    ops.layernorm_fwd(xw[:, :D], gam.to(DEV), bet.to(DEV), 1e-5, y)
+    torch.testing.assert_close(y.cpu(), ref, atol=1e-5, rtol=1e-5)
     g = ops.gather_rows(x.to(DEV), idx.to(DEV), torch.empty(5, D, dtype=torch.float16, device=DEV))
     assert torch.equal(g.cpu(), x[idx.long()])
     BT, HW = 3, 16
