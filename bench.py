@@ -528,7 +528,8 @@ def main():
                                       f"B={B}/GPU, mask_ratio=0.8, bf16 MFMA + fp32 accumulate/master (BASELINE configs[1])",
                           "global_batch": total_batch, "parallelism": f"dp{world}", "drop_path": 0.1, "optimizer": "AdamW(0.9,0.95) wd 0.05",
                           "launch": "hip_graph" if graphed is not None else "eager",
-                          "schedule": "teacher one batch ahead of the student (own stream)" if ahead is not None else "teacher then student"},
+                          "schedule": "teacher one batch ahead of the student (own stream)" if ahead is not None else "teacher then student",
+                          "teacher_residual_rows": {False: "f32", True: "bf16", "f16": "f16"}[teacher.runtime().res16]},
                "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "hw_queues": _HWQ,
                "final_loss": round(loss_v, 5), "final_grad_norm": round(gn_v, 5),
                "host_enqueue_ms_per_step": round(t_enq / a.steps * 1e3, 3),
