@@ -178,7 +178,10 @@ class _TeacherRuntime:
         #               attention moves by up to 1e-2 absolute -- never the default
         #   "0"/"f32"   f32 rows, what the reference's autocast path keeps (x + fp16 branch output -> fp32)
         mode = os.environ.get("UNITE_TEACHER_RES16", self.DEFAULT_RES16).lower()
-        self.res16 = {"0": False, "": False, "f32": False, "1": True, "bf16": True, "f16": "f16"}[mode]
+        kinds = {"0": False, "": False, "f32": False, "1": True, "bf16": True, "f16": "f16"}
+        if mode not in kinds:
+            raise ValueError(f"UNITE_TEACHER_RES16={mode!r}: expected f16, bf16 (or 1), f32 (or 0)")
+        self.res16 = kinds[mode]
         self.min_frames_per_stream = 64
         self._side = []
         # the flat parameter buffer and its bf16 shadow were just built on the CURRENT stream: the first forward may come from another one
