@@ -21,8 +21,14 @@
 namespace {
 
 // ------------------------------------------------------------------------------------ forward
-template <int NT16>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
+// NW waves per workgroup share one head's K / V image (two workgroups fit a CU either way: the LDS image decides).  NW = 8 doubles the waves per
+// SIMD (2 -> 4) at a 128-register budget, so the q fragments are fetched one tile ahead instead of all up front.  Round 4, alone on MI355X:
+// N = 197 (the teacher's last block, 3072 heads) 105 -> 91 us; N = 320 (student, 384 heads) does not fit 128 registers with the whole score row
+// held and a two-range form with a rescale measured 26.6 against 25.7 us -- it stays at NW = 4.  (Shader-clock stamps at N = 320: 12.1 k cycles of
+// K / V staging at the CU's fill rate before the first product, then 4.7-5.9 k per q-tile: scores 1.6 k, soft-max 0.6 k, P V 2.7 k -- the
+// transposing V reads --, store 1.0 k.)
+template <int NT16, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2))) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
                                                           int N, int H, float scale, uint32_t qkv_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = NT16 * 16;
@@ -33,30 +39,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const int b = blockIdx.x / H, h = blockIdx.x % H, HD = H * 64, ld = 3 * HD;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)qkv_bytes, 0x00020000);
     const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
-    stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
-    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
-    // this wave's query fragments (q-tiles wave, wave + 4, ...) are fetched under the K / V staging: a global load at the top of
-    // every q-tile would expose a full HBM round trip (~2 us) per ~0.6 us of work
-    constexpr int MAXQ = (NT16 + 3) / 4;
-    bf16x8 qfr[MAXQ][2];
-#pragma unroll
-    for (int qi = 0; qi < MAXQ; ++qi) {
-        const int qc = min((wave + 4 * qi) * 16 + c, N - 1);
+    stage_rows(rs, Ks, NK, N, base_k, ld, wave, NW, lane);
+    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, NW, lane);
+    // this wave's query fragments (q-tiles wave, wave + NW, ...) are fetched under the K / V staging (NW = 4: all of them; NW = 8: the first,
+    // then one tile ahead): a global load at the top of every q-tile would expose a full HBM round trip (~2 us) per ~0.6 us of work
+    constexpr int MAXQ = (NT16 + NW - 1) / NW;
+    constexpr int HELD = NW == 4 ? MAXQ : 1;
+    bf16x8 qfr[HELD][2];
+    auto fetch_q = [&](int qt, bf16x8& f0, bf16x8& f1) {
+        const int qc = min(qt * 16 + c, N - 1);
         const uint16_t* qp = qkv + (size_t)(b * N + qc) * ld + h * 64 + 8 * G;
-        qfr[qi][0] = *(const bf16x8*)qp;
-        qfr[qi][1] = *(const bf16x8*)(qp + 32);
-    }
+        f0 = *(const bf16x8*)qp;
+        f1 = *(const bf16x8*)(qp + 32);
+    };
+#pragma unroll
+    for (int qi = 0; qi < HELD; ++qi) fetch_q(wave + NW * qi, qfr[qi][0], qfr[qi][1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const float sl2 = scale * LOG2E;
     const int nqt = (N + 15) / 16;
-#pragma unroll
+    // NW = 4: the q-tile loop is unrolled (its fragments sit in registers by index); NW = 8: a real loop -- unrolled, the tail of one tile
+    // overlaps the head of the next and the kernel no longer fits 128 registers
+    constexpr int QUNROLL = NW == 4 ? MAXQ : 1;
+#pragma unroll QUNROLL
     for (int qi = 0; qi < MAXQ; ++qi) {
-        const int qt = wave + 4 * qi;
+        const int qt = wave + NW * qi;
         if (qt >= nqt) break;
         const int q = qt * 16 + c;
-        const bf16x8 qf0 = qfr[qi][0], qf1 = qfr[qi][1];
+        const bf16x8 qf0 = qfr[NW == 4 ? qi : 0][0], qf1 = qfr[NW == 4 ? qi : 0][1];
+        if (NW != 4 && qi + 1 < MAXQ) fetch_q(min(qt + NW, nqt - 1), qfr[0][0], qfr[0][1]);      // lands under this tile's work
         f32x4 st[NT16];
         float m = -INFINITY;
 #pragma unroll
@@ -103,8 +115,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int NT16>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+// NW as in the forward kernel: 8 waves per workgroup (4 per SIMD; the kernel needs 112-126 registers) measured 37.5 against 41.5 us at N = 320
+template <int NT16, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2))) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                              const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, float scale,
                                                              uint32_t qkv_bytes) {
@@ -117,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const int b = blockIdx.x / H, h = blockIdx.x % H, HD = H * 64, ld = 3 * HD;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (int)qkv_bytes, 0x00020000);
     const uint32_t base_k = (uint32_t)(b * N) * ld + HD + h * 64;
-    stage_rows(rs, Ks, NK, N, base_k, ld, wave, 4, lane);
-    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, 4, lane);
+    stage_rows(rs, Ks, NK, N, base_k, ld, wave, NW, lane);
+    stage_rows(rs, Vs, NK, N, base_k + HD, ld, wave, NW, lane);
 
     const float sl2 = scale * LOG2E;
     const int nqt = (N + 15) / 16;
@@ -139,11 +152,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     fetch(wave);             // under the K / V staging (waited for below together with it)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         const int q = qt * 16 + c;
         const bf16x8 qf0 = nq0, qf1 = nq1, df0 = nd0, df1 = nd1, of0 = no0, of1 = no1;
         const float l2 = nl2;
-        if (qt + 4 < nqt) fetch(qt + 4);
+        if (qt + NW < nqt) fetch(qt + NW);
         float dl = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dl += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
@@ -326,10 +339,21 @@ extern "C" int unite_attn_fwd(const void* qkv, void* out, float* lse, int32_t B,
     const int64_t bytes = (int64_t)B * N * 3 * H * 64 * 2;
     if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
     const int lds = nt * 16 * 128 * 2;
+    static const int nw_env = getenv("UNITE_ATTN_WAVES") ? atoi(getenv("UNITE_ATTN_WAVES")) : 0;      // 4 / 8: pin the waves per workgroup (A/B)
+    const bool eight = nt <= 16 && (nw_env ? nw_env == 8 : nt >= 14);      // above 256 keys the score row of a q-tile does not fit 128 registers
     ATTN_DISPATCH(nt, {
-        int e = set_lds<attn_fwd_kernel<NT16>>(lds);
+        if constexpr (NT16 <= 16) {
+            if (eight) {
+                int e = set_lds<attn_fwd_kernel<NT16, 8>>(lds);
+                if (e) return e;
+                hipLaunchKernelGGL((attn_fwd_kernel<NT16, 8>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                                   (uint16_t*)out, lse, N, H, scale, (uint32_t)bytes);
+                break;
+            }
+        }
+        int e = set_lds<attn_fwd_kernel<NT16, 4>>(lds);
         if (e) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<NT16>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, lse,
+        hipLaunchKernelGGL((attn_fwd_kernel<NT16, 4>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)out, lse,
                            N, H, scale, (uint32_t)bytes);
     });
     UNITE_LAUNCH_CHECK();
@@ -346,11 +370,21 @@ extern "C" int unite_attn_bwd(const void* qkv, const void* out, const void* dout
     if (bytes >= (int64_t)OOB_OFFSET) return UNITE_ENOSUP;
     const int lds = nt * 16 * 128 * 2;
     const int lds2 = lds + nt * 16 * 4 * 2;
+    static const int nw_env = getenv("UNITE_ATTN_WAVES") ? atoi(getenv("UNITE_ATTN_WAVES")) : 0;
+    const bool eight = nw_env ? nw_env == 8 : nt >= 14;
     ATTN_DISPATCH(nt, {
-        int e = set_lds<attn_bwd_dq_kernel<NT16>>(lds);
-        if (e) return e;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<NT16>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv,
-                           (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, N, H, scale, (uint32_t)bytes);
+        int e;
+        if (eight) {
+            e = set_lds<attn_bwd_dq_kernel<NT16, 8>>(lds);
+            if (e) return e;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<NT16, 8>), dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                               (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, N, H, scale, (uint32_t)bytes);
+        } else {
+            e = set_lds<attn_bwd_dq_kernel<NT16, 4>>(lds);
+            if (e) return e;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<NT16, 4>), dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)qkv,
+                               (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, N, H, scale, (uint32_t)bytes);
+        }
         UNITE_LAUNCH_CHECK();
         e = set_lds<attn_bwd_dkv_kernel<NT16, KTW>>(lds2);
         if (e) return e;
