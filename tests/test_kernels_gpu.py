@@ -575,7 +575,7 @@ def _attn_ref(qkv, B, N, H):
     return o, torch.logsumexp(s, -1), p
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 4, 2), (3, 5, 2), (2, 32, 1), (2, 197, 3), (2, 320, 2), (1, 33, 12), (1, 224, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 4, 2), (3, 5, 2), (2, 32, 1), (2, 197, 3), (2, 320, 2), (1, 33, 12), (1, 224, 1), (1, 250, 2), (2, 257, 1), (1, 288, 3), (2, 300, 1)])
 def test_attention_fwd_bwd(ops, B, N, H):
     qkv = bf(rnd(B * N, 3 * H * 64, seed=N, scale=1.0))
     qkv_g = qkv.float().clone().requires_grad_(True)
