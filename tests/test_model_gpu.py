@@ -873,6 +873,21 @@ def test_train_one_epoch_teacher_ahead_with_a_device_side_loader():
     assert st_a["grad_norm"] == st_s["grad_norm"]
 
 
+def test_teacher_residual_stream_types_error_statistics():
+    """What the DEFAULT residual-stream type of the frozen teacher (IEEE half) costs against the reference's fp32 rows, where 16 values of one fixture
+    cannot tell (test_teacher_tiny_vs_reference_golden): 12 seeded towers x 64 CLS-attention values each against the fp32 CPU oracle
+    (tools/teacher_stream_error.py; 24 towers in profiles/r04_teacher_stream_error.txt: 1.43e-3 / 1.45e-3 / 1.74e-3 rms for f16 / f32 / bf16 rows).
+    The f16 rows must be as accurate as the f32 rows (rms within 5 %, mean feature cosine within 2e-6), and better than the bf16 rows."""
+    from tools.teacher_stream_error import collect
+    st = collect(12)
+    rms = {k: v[0].pow(2).mean().sqrt().item() for k, v in st.items()}
+    cos = {k: v[2].mean().item() for k, v in st.items()}
+    assert rms["f32"] <= 2.0e-3                                   # values average 1 / 16: 3 % -- the bf16 operands of the score product
+    assert rms["f16"] <= 1.05 * rms["f32"], rms
+    assert rms["bf16"] >= 1.08 * rms["f16"], rms                  # the stream type that never became the default is measurably worse
+    assert abs(cos["f16"] - cos["f32"]) <= 2e-6 and cos["f16"] >= 0.9999, cos
+
+
 def test_teacher_bf16_residual_stream_vs_f32_stream():
     """UNITE_TEACHER_RES16=1 (opt-in: its attention error is outside the golden test's bound): the frozen teacher's residual
     stream, taps included, kept in bf16.  Against the f32 stream of the same weights and clips: CLS attention within 2e-2 absolute (five keys

@@ -15,9 +15,9 @@ from oracle.filler import fill_state_dict, make_videos  # noqa: E402
 from tests.shapes import teacher_shapes  # noqa: E402
 
 
-def main():
+def collect(seeds: int):
+    """{stream: (attention abs errors, attention relative errors, feature cosines)} over `seeds` seeded towers, each against the fp32 oracle"""
     from unite_amd.clip import VisionTransformer
-    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     cfg = O.TeacherCfg(input_resolution=64, patch_size=16, width=128, layers=3, heads=2, output_dim=64, clip_return_layers=(1, 2))
     acc = {m: dict(abs=[], rel=[], cos=[]) for m in ("f32", "bf16", "f16")}
     for seed in range(seeds):
@@ -35,9 +35,14 @@ def main():
             acc[name]["abs"].append(e.flatten())
             acc[name]["rel"].append((e / ref_a.abs()).flatten())
             acc[name]["cos"].append(torch.nn.functional.cosine_similarity(feats.cpu().flatten(0, -2), ref_f.flatten(0, -2), dim=-1))
-    print(f"# {seeds} models x 4 frames x 16 attention values (mean value {1 / 16:.4f}); features: {acc['f32']['cos'][0].numel()} rows per model")
-    for name, a in acc.items():
-        ab, rl, cs = torch.cat(a["abs"]), torch.cat(a["rel"]), torch.cat(a["cos"])
+    return {k: (torch.cat(v["abs"]), torch.cat(v["rel"]), torch.cat(v["cos"])) for k, v in acc.items()}
+
+
+def main():
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    stats = collect(seeds)
+    print(f"# {seeds} models x 4 frames x 16 attention values (mean value {1 / 16:.4f}); features: {stats['f32'][2].numel() // seeds} rows per model")
+    for name, (ab, rl, cs) in stats.items():
         print(f"{name:5s} attention abs err rms {ab.pow(2).mean().sqrt():.2e}  max {ab.max():.2e} | rel err rms {rl.pow(2).mean().sqrt():.4f}  max {rl.max():.4f}"
               f" | feature cosine min {cs.min():.6f}  mean {cs.mean():.7f}", flush=True)
 
