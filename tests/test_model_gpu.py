@@ -878,7 +878,7 @@ def test_teacher_residual_stream_types_error_statistics():
     cannot tell (test_teacher_tiny_vs_reference_golden): 12 seeded towers x 64 CLS-attention values each against the fp32 CPU oracle
     (tools/teacher_stream_error.py; 24 towers in profiles/r04_teacher_stream_error.txt: 1.43e-3 / 1.45e-3 / 1.74e-3 rms for f16 / f32 / bf16 rows).
     The f16 rows must be as accurate as the f32 rows (rms within 5 %, mean feature cosine within 2e-6), and better than the bf16 rows."""
-    from tools.teacher_stream_error import collect
+    from tests.teacher_stream_stats import collect
     st = collect(12)
     rms = {k: v[0].pow(2).mean().sqrt().item() for k, v in st.items()}
     cos = {k: v[2].mean().item() for k, v in st.items()}
