@@ -96,7 +96,7 @@ typedef struct unite_gemm_args {
     int32_t plan_persistent;                    /* as unite_gemm_set_policy, for THIS launch only */
     float   plan_sharing;                       /* as unite_gemm_set_sharing, for THIS launch only */
     int32_t residual_bf16;                      /* 1: `residual` points at bf16 [M,N] (the frozen teacher's bf16 residual stream).
-                                                   2: `residual` points at IEEE-half [M,N] AND the 16-bit `out` is written as IEEE half
+                                                   2: `residual` points at IEEE-half [M,N] AND the 16-bit `out` is written as IEEE half, saturating at +-65504
                                                    (the f16 residual stream OpenAI's CLIP runs with; out_f32, out_bf16_copy, colsum_out and
                                                    act must be 0 / NULL then) */
     float* rowsum_a_out;                        /* optional f32 [M]: rowsum_a_out[m] (+)= sum_k op(A)[m,k] -- for a weight gradient

@@ -444,6 +444,14 @@ def test_gemm_f16_residual_stream(ops, M, N, K):
     ops.gemm(a.to(DEV)[r0:], w.to(DEV), wide_o[r0:, 16:16 + N], bias=bias.to(DEV), residual=wide_r[r0:, 8:8 + N])
     torch.testing.assert_close(wide_o[r0:, 16:16 + N].float().cpu(), ref[r0:], atol=4e-3, rtol=1e-3)
     assert torch.isnan(wide_o[:, :16]).all() and torch.isnan(wide_o[:, 16 + N:]).all() and torch.isnan(wide_o[:r0]).all()
+    if M == 330:          # values beyond the half range saturate instead of becoming inf
+        big = torch.zeros(M, N, dtype=torch.float16)
+        big[3, 5], big[7, 9] = 60000.0, -60000.0
+        hot = torch.zeros(N)
+        hot[5], hot[9] = 30000.0, -30000.0
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(a.to(DEV), w.to(DEV), out, bias=hot.to(DEV), residual=big.to(DEV))
+        assert torch.isfinite(out).all() and out[3, 5].item() == 65504.0 and out[7, 9].item() == -65504.0
     with pytest.raises(Exception):          # an f16 output without the f16 residual is not a form of the kernel
         ops.gemm(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV))
     with pytest.raises(Exception):

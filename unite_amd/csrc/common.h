@@ -40,6 +40,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // IEEE half pairs (the frozen teacher's f16 residual stream): round-to-nearest-even packs, exact unpacks
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    // saturating: a stream value beyond the half range becomes +-65504, not inf (an inf would turn its whole row into NaN in the next LayerNorm)
+    lo = __builtin_fminf(__builtin_fmaxf(lo, -65504.0f), 65504.0f);      // v_med3_f32
+    hi = __builtin_fminf(__builtin_fmaxf(hi, -65504.0f), 65504.0f);
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
